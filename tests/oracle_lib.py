@@ -1,0 +1,129 @@
+"""ctypes binding of the oracle (oracle/_build/liboracle.so).  Test infrastructure only."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rt = importlib.import_module("ray-tracer_amd")
+capi = importlib.import_module("ray-tracer_amd.capi")
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+        l = C.CDLL(path)
+        l.orc_scene_create.restype = C.c_void_p
+        l.orc_scene_create.argtypes = [C.POINTER(capi.SceneDesc)]
+        l.orc_scene_destroy.argtypes = [C.c_void_p]
+        l.orc_bvh_build.argtypes = [C.c_void_p, C.POINTER(capi.BvhOptions)]
+        for fn in ("orc_bvh_num_levels", "orc_bvh_num_leaves", "orc_bvh_num_nodes", "orc_bvh_num_ids"):
+            getattr(l, fn).argtypes = [C.c_void_p]
+        l.orc_bvh_export.argtypes = [C.c_void_p] * 4
+        l.orc_intersect_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(capi.Features), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        l.orc_visibility_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.POINTER(capi.Features), C.c_void_p]
+        l.orc_camera_rays.argtypes = [C.POINTER(capi.Camera), C.c_int32, C.c_int32, C.c_void_p]
+        l.orc_render.argtypes = [C.c_void_p, C.POINTER(capi.Camera), C.POINTER(capi.Light), C.c_int32, C.POINTER(capi.Features), C.POINTER(capi.Params),
+                                 C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(capi.Stats)]
+        l.orc_bloom.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(capi.Params)]
+        for fn in ("orc_kat_aabb", "orc_kat_tri", "orc_kat_shade", "orc_kat_env", "orc_kat_interp"):
+            getattr(l, fn).argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        l.orc_kat_texel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        l.orc_kat_clamp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        l.orc_rng_u32.restype = C.c_uint32
+        l.orc_rng_u32.argtypes = [C.c_uint32] * 5
+        _LIB = l
+    return _LIB
+
+
+class OracleScene:
+    def __init__(self, scene, sah=False, max_level=32, sah_bins=64):
+        self.scene = scene
+        self.h = lib().orc_scene_create(C.byref(scene.desc))
+        opt = capi.BvhOptions(int(sah), max_level, sah_bins)
+        lib().orc_bvh_build(self.h, C.byref(opt))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_scene_destroy(self.h)
+            self.h = None
+
+    def levels_leaves(self):
+        return lib().orc_bvh_num_levels(self.h), lib().orc_bvh_num_leaves(self.h)
+
+    def export(self):
+        n = lib().orc_bvh_num_nodes(self.h)
+        meta = np.zeros((n, 4), np.int32)
+        box = np.zeros((n, 6), np.float32)
+        ids = np.zeros(lib().orc_bvh_num_ids(self.h), np.int32)
+        lib().orc_bvh_export(self.h, meta.ctypes.data, box.ctypes.data, ids.ctypes.data)
+        return meta, box, ids
+
+    def intersect(self, rays, feats):
+        rays = np.ascontiguousarray(rays, dtype=capi.RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], capi.HIT_DTYPE)
+        b, t = C.c_uint64(), C.c_uint64()
+        lib().orc_intersect_batch(self.h, rays.ctypes.data, rays.shape[0], C.byref(feats), hits.ctypes.data, C.byref(b), C.byref(t))
+        self.last_counts = (b.value, t.value)
+        return hits
+
+    def visibility(self, rays, samples, feats):
+        rays = np.ascontiguousarray(rays, dtype=capi.RAY_DTYPE)
+        samples = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros((rays.shape[0], samples.shape[0]), np.uint8)
+        lib().orc_visibility_batch(self.h, rays.ctypes.data, rays.shape[0], samples.ctypes.data, samples.shape[0], C.byref(feats), out.ctypes.data)
+        return out
+
+    def render(self, camera, feats, params, width, height, lights=None, row_begin=0, row_end=None, row_step=1, threads=0):
+        row_end = height if row_end is None else row_end
+        arr, n = self.scene.light_array(lights)
+        img = np.zeros((row_end - row_begin, width, 3), np.float32)
+        stats = capi.Stats()
+        lib().orc_render(self.h, C.byref(camera), arr, n, C.byref(feats), C.byref(params), width, height, row_begin, row_end, row_step, threads,
+                         img.ctypes.data, C.byref(stats))
+        return img, stats
+
+
+def camera_rays(camera, width, height):
+    rays = np.zeros(width * height, capi.RAY_DTYPE)
+    lib().orc_camera_rays(C.byref(camera), width, height, rays.ctypes.data)
+    return rays
+
+
+def bloom(image, params):
+    img = np.ascontiguousarray(image, dtype=np.float32).copy()
+    lib().orc_bloom(img.ctypes.data, img.shape[1], img.shape[0], C.byref(params))
+    return img
+
+
+def kat(name, inp, out_cols):
+    inp = np.ascontiguousarray(inp, dtype=np.float32)
+    out = np.zeros((inp.shape[0], out_cols), np.float32)
+    getattr(lib(), "orc_kat_" + name)(inp.ctypes.data, inp.shape[0], out.ctypes.data)
+    return out
+
+
+CAM_A = dict(fov_deg=50.0, distance=3.0, look_at=(0.0, 0.0, 0.0), rot_deg=(20.0, 20.0, 0.0))
+CAM_B = dict(fov_deg=60.0, distance=2.5, look_at=(0.1, -0.05, 0.05), rot_deg=(-15.0, 140.0, 0.0))
+SIZE_A = (72, 48)
+SIZE_B = (48, 48)
+
+
+def golden(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+def rays_from_array(a):
+    a = np.asarray(a, dtype=np.float32).reshape(-1, 7)
+    rays = np.zeros(a.shape[0], capi.RAY_DTYPE)
+    rays["origin"] = a[:, 0:3]
+    rays["direction"] = a[:, 3:6]
+    rays["t"] = a[:, 6]
+    return rays
