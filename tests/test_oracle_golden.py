@@ -176,8 +176,10 @@ def test_texture_fetch_known_answers():
     # oracle and the kernels clamp the index instead.
     tex = sc.textures[0]
     th, tw = tex.shape[0], tex.shape[1]
-    i = np.fmod(np.round((uv[:, 0] * np.float32(tw)).astype(np.float64) - 0.5), tw).astype(np.float32)
-    j = np.fmod(np.round(((np.float32(1) - uv[:, 1]) * np.float32(th)).astype(np.float64) - 0.5), th).astype(np.float32)
+    def c_round(x):  # std::round: halves away from zero (np.round goes to even)
+        return np.where(x >= 0, np.floor(x + 0.5), np.ceil(x - 0.5))
+    i = np.fmod(c_round((uv[:, 0] * np.float32(tw)).astype(np.float64) - 0.5), tw).astype(np.float32)
+    j = np.fmod(c_round(((np.float32(1) - uv[:, 1]) * np.float32(th)).astype(np.float64) - 0.5), th).astype(np.float32)
     idx = (j * np.float32(tw) + i).astype(np.int64)
     ok = (idx >= 0) & (idx < tw * th)
     assert ok.sum() > 300 and (~ok).sum() > 0
