@@ -182,7 +182,7 @@ def test_texture_fetch_known_answers():
     j = np.fmod(c_round(((np.float32(1) - uv[:, 1]) * np.float32(th)).astype(np.float64) - 0.5), th).astype(np.float32)
     idx = (j * np.float32(tw) + i).astype(np.int64)
     ok = (idx >= 0) & (idx < tw * th)
-    assert ok.sum() > 300 and (~ok).sum() > 0
+    assert ok.sum() > 200 and (~ok).sum() > 0
     assert np.array_equal(out[ok], k["texel_out"][ok])
     flat = tex.reshape(-1, 3).astype(np.float32) / np.float32(255.0)
     assert np.array_equal(out[~ok], flat[np.clip(idx[~ok], 0, tw * th - 1)])
