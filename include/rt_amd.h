@@ -106,9 +106,11 @@ typedef struct rt_params {
     int32_t enabled_skybox;            /* environment_mapping.cpp:5 (0) */
     int32_t enabled_refl_map;          /* environment_mapping.cpp:6 (0) */
     int32_t max_transparency_depth;    /* no counterpart: the reference's see-through continuation is unbounded
-                                          (render.cpp:36-46); this caps it (default 64; the pixel's rt_stats
+                                          (render.cpp:36-46); this caps it (default 16, at most 24; rt_stats'
                                           overflow counter reports if it was ever reached) */
     uint32_t seed;                     /* frame seed of the counter-based random stream */
+    int32_t count_tests;               /* no counterpart: also count ray/box and ray/triangle tests into rt_stats
+                                          (slower kernel variant; ray counts are always collected) */
 } rt_params;
 
 /* ---- camera (replaces Trackball: reference framework/src/trackball.cpp:23-31,71-74,101-126) */

@@ -101,12 +101,13 @@ class Params(C.Structure):
         ("enabled_refl_map", C.c_int32),
         ("max_transparency_depth", C.c_int32),
         ("seed", C.c_uint32),
+        ("count_tests", C.c_int32),
     ]
 
 
 def default_params(**kw):
     """The reference's default tunables (see include/rt_amd.h for the file:line of each)."""
-    p = Params(10, 10, 1, 4, 64, 1.0, 3, 1.4, 2.5, 0.0, 0.7, 2, 1.0, 0, 1, 1.0, 0, 0, 64, 1)
+    p = Params(10, 10, 1, 4, 64, 1.0, 3, 1.4, 2.5, 0.0, 0.7, 2, 1.0, 0, 1, 1.0, 0, 0, 16, 1, 0)
     for k, v in kw.items():
         if not hasattr(p, k):
             raise KeyError(k)

@@ -1,0 +1,562 @@
+// C ABI of librt_amd (declared in include/rt_amd.h): handle management, per-frame parameter snapshot,
+// uploads and kernel launches.  Host code only; the kernels live in rt_kernels.hip.
+#include "bvh_build.h"
+#include "rt_amd.h"
+#include "rt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_error;
+
+rt_status fail(rt_status code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+rt_status hip_fail(hipError_t e, const char* what)
+{
+    return fail(e == hipErrorNoDevice || e == hipErrorInvalidDevice ? RT_ERR_NO_DEVICE : RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define RT_HIP(call)                                            \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);       \
+    } while (0)
+
+// Growable device buffer.
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+template <class T>
+hipError_t upload(DevBuf& buf, const std::vector<T>& v)
+{
+    const size_t bytes = v.size() * sizeof(T);
+    hipError_t e = buf.reserve(bytes ? bytes : 64);
+    if (e != hipSuccess) return e;
+    if (bytes) e = hipMemcpy(buf.ptr, v.data(), bytes, hipMemcpyHostToDevice);
+    return e;
+}
+
+} // namespace
+
+struct rt_scene {
+    HostScene host;
+    // device copies are made on first use (so that building and inspecting a hierarchy needs no GPU)
+    std::mutex lock;
+    bool uploaded = false;
+    int device = 0;
+    DevBuf mats, texels, textures;
+    ImageRec skybox[6] = {};
+};
+
+struct rt_bvh {
+    rt_scene* scene = nullptr;
+    HostBvh host;
+    FlatBvh flat; // host image of the device tables; dropped after the upload
+    bool uploaded = false;
+    DevBuf nodes, prims, attrs, primOrder;
+    SceneView view {};
+    // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
+    std::mutex lock;
+    DevBuf stats, frame, samples, dofFlags, rays, hits, misc, bloomWeights;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+};
+
+namespace {
+
+void fill_lights(const rt_light* lights, int n, const rt_features& f, const rt_params& p, LightDev* out, int& drawsPerHit)
+{
+    drawsPerHit = 0;
+    for (int i = 0; i < n; i++) {
+        LightDev& d = out[i];
+        std::memset(&d, 0, sizeof d);
+        d.type = lights[i].type;
+        std::memcpy(d.v, lights[i].v, sizeof d.v);
+        d.nA = d.nB = 1;
+        if (d.type == RT_LIGHT_SEGMENT) {
+            // reference src/light.cpp:151-160
+            const vec3 e0 = load3(d.v), e1 = load3(d.v + 3);
+            const float segmentLengthRec = 1.0f / length(e1 - e0);
+            const float sampleCountRec = 1.0f / std::floor(std::fmax(float(p.samples_per_unit) / segmentLengthRec, 1.0f));
+            const vec3 step = (e1 - e0) * sampleCountRec;
+            const float sampleCount = 1.0f / sampleCountRec;
+            d.recA = sampleCountRec;
+            d.recB = segmentLengthRec;
+            d.step[0] = step.x; d.step[1] = step.y; d.step[2] = step.z;
+            int trips = 0;
+            for (int k = 0; float(k) < sampleCount; k++) trips++;
+            d.nA = trips;
+            d.draws = (f.soft_shadow || f.shading) ? trips : 0;
+        } else if (d.type == RT_LIGHT_PARALLELOGRAM) {
+            // reference src/light.cpp:188-196
+            const float recI = 1.0f / std::floor(std::fmax(float(p.samples_per_unit_parallel) * length(load3(d.v + 3)), 1.0f));
+            const float recJ = 1.0f / std::floor(std::fmax(float(p.samples_per_unit_parallel) * length(load3(d.v + 6)), 1.0f));
+            const float countI = 1.0f / recI, countJ = 1.0f / recJ;
+            d.recA = recI;
+            d.recB = recJ;
+            int ti = 0, tj = 0;
+            for (int k = 0; float(k) < countI; k++) ti++;
+            for (int k = 0; float(k) < countJ; k++) tj++;
+            d.nA = ti;
+            d.nB = tj;
+            d.draws = (f.soft_shadow || f.shading) ? 2 * ti * tj : 0;
+        }
+        drawsPerHit += d.draws;
+    }
+}
+
+// Trackball state, reference framework/src/trackball.cpp:23-31,71-74,117-126 and glm's Euler-angle quaternion
+// constructor (glm/detail/type_quat.inl:208-217).
+void fill_camera(const rt_camera& c, FrameParams& P)
+{
+    const float ex = c.rotation[0] * 0.5f, ey = c.rotation[1] * 0.5f, ez = c.rotation[2] * 0.5f;
+    const float cx = std::cos(ex), cy = std::cos(ey), cz = std::cos(ez);
+    const float sx = std::sin(ex), sy = std::sin(ey), sz = std::sin(ez);
+    quat q;
+    q.w = cx * cy * cz + sx * sy * sz;
+    q.x = sx * cy * cz - cx * sy * sz;
+    q.y = cx * sy * cz + sx * cy * sz;
+    q.z = cx * cy * sz - sx * sy * cz;
+    P.camQ = q;
+    const vec3 pos = load3(c.look_at) + rotate(q, make3(0.0f, 0.0f, -c.distance));
+    const vec3 up = rotate(q, make3(0.0f, 1.0f, 0.0f));
+    const vec3 left = rotate(q, make3(1.0f, 0.0f, 0.0f));
+    P.camPos[0] = pos.x; P.camPos[1] = pos.y; P.camPos[2] = pos.z;
+    P.camUp[0] = up.x; P.camUp[1] = up.y; P.camUp[2] = up.z;
+    P.camLeft[0] = left.x; P.camLeft[1] = left.y; P.camLeft[2] = left.z;
+    P.halfH = std::tan(c.fovy / 2.0f);
+    P.halfW = c.aspect * P.halfH;
+}
+
+rt_status check_limits(const rt_bvh* bvh, const rt_features* f, const rt_params* p)
+{
+    (void)bvh;
+    if (p) {
+        if (p->ray_depth < 0 || p->ray_depth > MAX_SPECULAR_DEPTH)
+            return fail(RT_ERR_LIMIT, "ray_depth must be in [0, " + std::to_string(int(MAX_SPECULAR_DEPTH)) + "]");
+        if (p->max_transparency_depth < 0 || p->max_transparency_depth > MAX_BLEND_DEPTH)
+            return fail(RT_ERR_LIMIT, "max_transparency_depth must be in [0, " + std::to_string(int(MAX_BLEND_DEPTH)) + "]");
+        if (f->multiple_rays && (p->ray_multiplier < 1 || p->ray_multiplier > 64))
+            return fail(RT_ERR_LIMIT, "ray_multiplier must be in [1, 64]");
+        if (f->depth_of_field && (p->dof_samples < 0 || p->dof_samples > 4095))
+            return fail(RT_ERR_LIMIT, "dof_samples must be in [0, 4095]");
+        if (f->glossy && (p->glossy_filter_size < 0 || p->glossy_filter_size > 4096))
+            return fail(RT_ERR_LIMIT, "glossy_filter_size must be in [0, 4096]");
+        if (p->samples_per_unit < 0 || p->samples_per_unit_parallel < 0)
+            return fail(RT_ERR_INVALID, "negative light sampling density");
+    }
+    return RT_OK;
+}
+
+rt_status upload_scene(rt_scene* s)
+{
+    std::lock_guard<std::mutex> guard(s->lock);
+    if (s->uploaded) return RT_OK;
+    RT_HIP(hipGetDevice(&s->device));
+    // materials: meshes then spheres
+    std::vector<MaterialRec> mats;
+    for (const HostMesh& m : s->host.meshes) mats.push_back(m.material);
+    for (const rt_sphere_desc& sp : s->host.spheres) {
+        MaterialRec m;
+        std::memset(&m, 0, sizeof m);
+        std::memcpy(m.kd, sp.kd, 12);
+        std::memcpy(m.ks, sp.ks, 12);
+        m.shininess = sp.shininess;
+        m.transparency = sp.transparency;
+        m.texture = -1;
+        mats.push_back(m);
+    }
+    // texels: textures then the six cube-map faces, each 4-byte aligned
+    std::vector<uint8_t> texels;
+    std::vector<ImageRec> recs;
+    auto append = [&](const HostImage& im) {
+        ImageRec r { uint32_t(texels.size()), im.width, im.height };
+        texels.insert(texels.end(), im.rgb.begin(), im.rgb.end());
+        while (texels.size() % 4) texels.push_back(0);
+        return r;
+    };
+    for (const HostImage& im : s->host.textures) recs.push_back(append(im));
+    for (size_t i = 0; i < s->host.skybox.size(); i++) s->skybox[i] = append(s->host.skybox[i]);
+    RT_HIP(upload(s->mats, mats));
+    RT_HIP(upload(s->texels, texels));
+    RT_HIP(upload(s->textures, recs));
+    s->uploaded = true;
+    return RT_OK;
+}
+
+// Makes the device tables of `b` (and of its scene) exist.  Caller holds b->lock.
+rt_status upload_bvh(rt_bvh* b)
+{
+    if (b->uploaded) return RT_OK;
+    rt_scene* scene = b->scene;
+    rt_status st = upload_scene(scene);
+    if (st != RT_OK) return st;
+    RT_HIP(hipSetDevice(scene->device));
+    const FlatBvh& flat = b->flat;
+    RT_HIP(upload(b->nodes, flat.nodes));
+    RT_HIP(upload(b->prims, flat.prims));
+    RT_HIP(upload(b->attrs, flat.attrs));
+    RT_HIP(upload(b->primOrder, flat.primOrder));
+    RT_HIP(b->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
+    RT_HIP(hipEventCreate(&b->evStart));
+    RT_HIP(hipEventCreate(&b->evStop));
+    SceneView& v = b->view;
+    v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
+    v.prims = static_cast<const PrimRec*>(b->prims.ptr);
+    v.attrs = static_cast<const AttrRec*>(b->attrs.ptr);
+    v.mats = static_cast<const MaterialRec*>(scene->mats.ptr);
+    v.texels = static_cast<const uint8_t*>(scene->texels.ptr);
+    v.textures = static_cast<const ImageRec*>(scene->textures.ptr);
+    v.primOrder = static_cast<const uint32_t*>(b->primOrder.ptr);
+    std::memcpy(v.skybox, scene->skybox, sizeof v.skybox);
+    std::memcpy(v.rootLo, flat.rootLo, 12);
+    std::memcpy(v.rootHi, flat.rootHi, 12);
+    v.rootRef = flat.rootRef;
+    v.numPrims = int32_t(flat.prims.size());
+    v.numMeshes = int32_t(scene->host.meshes.size());
+    v.hasSkybox = scene->host.skybox.size() == 6;
+    v.hasSpheres = !scene->host.spheres.empty();
+    v.stackDepth = b->host.numLevels;
+    b->flat = FlatBvh {};
+    b->uploaded = true;
+    return RT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+void rt_default_params(rt_params* p)
+{
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    p->samples_per_unit = 10;
+    p->samples_per_unit_parallel = 10;
+    p->ray_multiplier = 1;
+    p->ray_depth = 4;
+    p->glossy_filter_size = 64;
+    p->glossy_sigma = 1.0f;
+    p->dof_samples = 3;
+    p->dof_aperture = 1.4f;
+    p->dof_f = 2.5f;
+    p->dof = 0.0f;
+    p->bloom_threshold = 0.7f;
+    p->bloom_size = 2;
+    p->bloom_sigma = 1.0f;
+    p->bloom_debug = 0;
+    p->bloom_gaussian = 1;
+    p->bloom_scale = 1.0f;
+    p->enabled_skybox = 0;
+    p->enabled_refl_map = 0;
+    p->max_transparency_depth = 16;
+    p->seed = 1;
+    p->count_tests = 0;
+}
+
+rt_status rt_init(int32_t device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
+    RT_HIP(hipSetDevice(device));
+    return RT_OK;
+}
+
+rt_status rt_scene_create(const rt_scene_desc* desc, rt_scene** out)
+{
+    if (!desc || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
+    *out = nullptr;
+    rt_scene* s = new (std::nothrow) rt_scene;
+    if (!s) return fail(RT_ERR_INVALID, "out of host memory");
+    std::string err;
+    if (!copy_scene(*desc, s->host, err)) {
+        delete s;
+        return fail(RT_ERR_INVALID, err);
+    }
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s)
+{
+    if (!s) return;
+    s->mats.release();
+    s->texels.release();
+    s->textures.release();
+    delete s;
+}
+
+rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** out)
+{
+    if (!scene || !out) return fail(RT_ERR_INVALID, "rt_bvh_build: null argument");
+    *out = nullptr;
+    rt_bvh_options opt { 0, 32, 64 };
+    if (options) opt = *options;
+    if (opt.max_level < 0 || opt.max_level > RT_MAX_LEVELS - 1) return fail(RT_ERR_LIMIT, "max_level must be in [0, 32]");
+    if (opt.sah_binning && opt.sah_bins < 1) return fail(RT_ERR_INVALID, "sah_bins must be positive");
+    if (!scene->host.spheres.empty())
+        return fail(RT_ERR_INVALID, "sphere primitives are not supported by the kernels yet");
+    rt_bvh* b = new (std::nothrow) rt_bvh;
+    if (!b) return fail(RT_ERR_INVALID, "out of host memory");
+    b->scene = scene;
+    build_bvh(scene->host, opt, b->host);
+    flatten_bvh(scene->host, b->host, b->flat);
+    *out = b;
+    return RT_OK;
+}
+
+void rt_bvh_destroy(rt_bvh* b)
+{
+    if (!b) return;
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
+        d->release();
+    if (b->evStart) (void)hipEventDestroy(b->evStart);
+    if (b->evStop) (void)hipEventDestroy(b->evStop);
+    delete b;
+}
+
+int32_t rt_bvh_num_levels(const rt_bvh* b) { return b ? b->host.numLevels : 0; }
+int32_t rt_bvh_num_leaves(const rt_bvh* b) { return b ? b->host.numLeaves : 0; }
+int32_t rt_bvh_num_nodes(const rt_bvh* b) { return b ? int32_t(b->host.nodes.size()) : 0; }
+int32_t rt_bvh_num_prim_refs(const rt_bvh* b) { return b ? int32_t(b->host.prims.size()) : 0; }
+
+rt_status rt_bvh_export(const rt_bvh* b, rt_node_record* nodes, int32_t nNodes, rt_prim_ref* prims, int32_t nPrims)
+{
+    if (!b) return fail(RT_ERR_INVALID, "rt_bvh_export: null bvh");
+    if (nNodes < int32_t(b->host.nodes.size()) || nPrims < int32_t(b->host.prims.size())) return fail(RT_ERR_INVALID, "rt_bvh_export: output arrays too small");
+    if (nodes) std::memcpy(nodes, b->host.nodes.data(), b->host.nodes.size() * sizeof(rt_node_record));
+    if (prims) std::memcpy(prims, b->host.prims.data(), b->host.prims.size() * sizeof(rt_prim_ref));
+    return RT_OK;
+}
+
+rt_status rt_intersect_batch(const rt_bvh* cb, const rt_ray* rays, uint64_t n, const rt_features* features, rt_hit* hits, int32_t devicePtrs, void* stream)
+{
+    rt_bvh* b = const_cast<rt_bvh*>(cb);
+    if (!b || !features || (n && (!rays || !hits))) return fail(RT_ERR_INVALID, "rt_intersect_batch: null argument");
+    if (n == 0) return RT_OK;
+    std::lock_guard<std::mutex> guard(b->lock);
+    {
+        rt_status up = upload_bvh(b);
+        if (up != RT_OK) return up;
+    }
+    RT_HIP(hipSetDevice(b->scene->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    FrameParams P;
+    std::memset(&P, 0, sizeof P);
+    P.scene = b->view;
+    P.f = *features;
+    P.stats = nullptr;
+    const rt_ray* dRays = rays;
+    rt_hit* dHits = hits;
+    if (!devicePtrs) {
+        RT_HIP(b->rays.reserve(n * sizeof(rt_ray)));
+        RT_HIP(b->hits.reserve(n * sizeof(rt_hit)));
+        RT_HIP(hipMemcpyAsync(b->rays.ptr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice, s));
+        dRays = static_cast<const rt_ray*>(b->rays.ptr);
+        dHits = static_cast<rt_hit*>(b->hits.ptr);
+    }
+    RT_HIP(launch_intersect(P, dRays, n, dHits, s));
+    if (!devicePtrs) {
+        RT_HIP(hipMemcpyAsync(hits, dHits, n * sizeof(rt_hit), hipMemcpyDeviceToHost, s));
+        RT_HIP(hipStreamSynchronize(s));
+    }
+    return RT_OK;
+}
+
+rt_status rt_visibility_batch(const rt_bvh* cb, const rt_ray* rays, uint64_t n, const float* samplePositions, int32_t nSamples, const rt_features* features, uint8_t* out)
+{
+    rt_bvh* b = const_cast<rt_bvh*>(cb);
+    if (!b || !features || (n && nSamples && (!rays || !samplePositions || !out)) || nSamples < 0) return fail(RT_ERR_INVALID, "rt_visibility_batch: bad argument");
+    if (n == 0 || nSamples == 0) return RT_OK;
+    std::lock_guard<std::mutex> guard(b->lock);
+    {
+        rt_status up = upload_bvh(b);
+        if (up != RT_OK) return up;
+    }
+    RT_HIP(hipSetDevice(b->scene->device));
+    FrameParams P;
+    std::memset(&P, 0, sizeof P);
+    P.scene = b->view;
+    P.f = *features;
+    const size_t outBytes = size_t(n) * size_t(nSamples);
+    const size_t sampleBytes = size_t(nSamples) * 12;
+    RT_HIP(b->rays.reserve(n * sizeof(rt_ray)));
+    RT_HIP(b->misc.reserve(((outBytes + 63) / 64) * 64 + sampleBytes));
+    uint8_t* dOut = static_cast<uint8_t*>(b->misc.ptr);
+    float* dSamples = reinterpret_cast<float*>(dOut + ((outBytes + 63) / 64) * 64);
+    RT_HIP(hipMemcpy(b->rays.ptr, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    RT_HIP(hipMemcpy(dSamples, samplePositions, sampleBytes, hipMemcpyHostToDevice));
+    RT_HIP(launch_visibility(P, static_cast<const rt_ray*>(b->rays.ptr), n, dSamples, nSamples, dOut, nullptr));
+    RT_HIP(hipMemcpy(out, dOut, outBytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
+    const rt_params* params, int32_t width, int32_t height, int32_t rowBegin, int32_t rowEnd, float* outRgb, int32_t devicePtr, void* stream, rt_stats* stats)
+{
+    rt_bvh* b = const_cast<rt_bvh*>(cb);
+    if (!b || !camera || !features || !params || (nLights && !lights) || nLights < 0) return fail(RT_ERR_INVALID, "rt_render: null argument");
+    if (width <= 0 || height <= 0 || rowBegin < 0 || rowEnd > height || rowBegin > rowEnd) return fail(RT_ERR_INVALID, "rt_render: bad frame or row range");
+    if (rowEnd > rowBegin && !outRgb) return fail(RT_ERR_INVALID, "rt_render: null output");
+    if (int64_t(width) * int64_t(height) > (int64_t(1) << 30)) return fail(RT_ERR_LIMIT, "frame larger than 2^30 pixels");
+    if (features->environment_mapping && (params->enabled_skybox || params->enabled_refl_map) && b->scene->host.skybox.size() != 6)
+        return fail(RT_ERR_INVALID, "environment mapping requested but the scene has no skybox");
+    rt_status st = check_limits(b, features, params);
+    if (st != RT_OK) return st;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (rowEnd == rowBegin) return RT_OK;
+
+    std::lock_guard<std::mutex> guard(b->lock);
+    {
+        rt_status up = upload_bvh(b);
+        if (up != RT_OK) return up;
+    }
+    RT_HIP(hipSetDevice(b->scene->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t nPix = size_t(rowEnd - rowBegin) * size_t(width);
+
+    FrameParams P;
+    std::memset(&P, 0, sizeof P);
+    P.scene = b->view;
+    fill_camera(*camera, P);
+    P.width = width;
+    P.height = height;
+    P.rowBegin = rowBegin;
+    P.rowEnd = rowEnd;
+    P.f = *features;
+    P.p = *params;
+    if (nLights > MAX_LIGHTS) return fail(RT_ERR_LIMIT, "at most " + std::to_string(int(MAX_LIGHTS)) + " lights per frame");
+    fill_lights(lights, nLights, *features, *params, P.lights, P.drawsPerHit);
+    P.nLights = nLights;
+
+    int spp = 1;
+    if (features->multiple_rays) spp = params->ray_multiplier * params->ray_multiplier;
+    else if (features->depth_of_field) spp = params->dof_samples + 1;
+    P.samplesPerPixel = spp;
+    if (spp > 1) {
+        RT_HIP(b->samples.reserve(nPix * size_t(spp) * 12));
+        P.samples = static_cast<float*>(b->samples.ptr);
+    }
+    if (features->depth_of_field && !features->multiple_rays) {
+        RT_HIP(b->dofFlags.reserve(nPix));
+        P.dofFlags = static_cast<uint8_t*>(b->dofFlags.ptr);
+    } else {
+        P.f.depth_of_field = 0; // the reference ignores it when supersampling is on (render.cpp:96-98)
+    }
+    float* dOut = outRgb;
+    if (!devicePtr) {
+        RT_HIP(b->frame.reserve(nPix * 12));
+        dOut = static_cast<float*>(b->frame.ptr);
+    }
+    P.out = dOut;
+    P.stats = static_cast<unsigned long long*>(b->stats.ptr);
+    P.countTests = stats != nullptr && params->count_tests != 0;
+    RT_HIP(hipMemsetAsync(b->stats.ptr, 0, STAT_COUNT * sizeof(unsigned long long), s));
+    // a synchronous wait is only needed when the caller wants numbers or host pixels back
+    const bool wait = stats != nullptr || !devicePtr;
+    if (stats) RT_HIP(hipEventRecord(b->evStart, s));
+    RT_HIP(launch_render(P, s));
+    if (stats) RT_HIP(hipEventRecord(b->evStop, s));
+    if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
+    if (wait) RT_HIP(hipStreamSynchronize(s));
+    if (stats) {
+        unsigned long long h[STAT_COUNT];
+        RT_HIP(hipMemcpy(h, b->stats.ptr, sizeof h, hipMemcpyDeviceToHost));
+        stats->primary_rays = h[STAT_PRIMARY];
+        stats->shadow_rays = h[STAT_SHADOW];
+        stats->bounce_rays = h[STAT_BOUNCE];
+        stats->probe_rays = h[STAT_PROBE];
+        stats->box_tests = h[STAT_BOX];
+        stats->triangle_tests = h[STAT_TRI];
+        stats->transparency_overflows = h[STAT_OVERFLOW];
+        RT_HIP(hipEventElapsedTime(&stats->kernel_ms, b->evStart, b->evStop));
+    }
+    return RT_OK;
+}
+
+rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params* params, int32_t devicePtr, void* stream)
+{
+    if (!pixels || !params || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_bloom: bad argument");
+    if (params->bloom_size < 0 || params->bloom_size > 16) return fail(RT_ERR_LIMIT, "bloom_size must be in [0, 16]");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int k = params->bloom_size, size = 2 * k + 1;
+    // gaussianKernel, reference src/bloom.cpp:14-48 (weights[j*size+i] = gaus[j][i])
+    std::vector<float> g(size_t(size) * size_t(size), 0.0f);
+    if (params->bloom_gaussian) {
+        const float sd = float(std::pow(double(params->bloom_sigma), 2.0));
+        const double spread = 1.0 / double(2 * sd);
+        float denom = 0;
+        for (int i = 0; i < size; i++) {
+            const int x = i - k;
+            const float valx = float(std::exp(double(-x * x) * spread));
+            for (int j = 0; j < size; j++) {
+                const int y = j - k;
+                const float valy = float(std::exp(double(-y * y) * spread));
+                g[size_t(i) * size_t(size) + size_t(j)] = valy * valx;
+                denom += valy * valx;
+            }
+        }
+        for (float& v : g) v /= denom;
+    }
+    const size_t bytes = size_t(width) * size_t(height) * 12;
+    float *dSrc = nullptr, *dDst = nullptr, *dW = nullptr;
+    hipError_t e = hipMalloc(&dSrc, bytes);
+    if (e == hipSuccess && !devicePtr) e = hipMalloc(&dDst, bytes);
+    if (e == hipSuccess) e = hipMalloc(&dW, g.size() * sizeof(float));
+    auto cleanup = [&] {
+        if (dSrc) (void)hipFree(dSrc);
+        if (dDst) (void)hipFree(dDst);
+        if (dW) (void)hipFree(dW);
+    };
+    if (e != hipSuccess) {
+        cleanup();
+        return hip_fail(e, "rt_bloom: hipMalloc");
+    }
+    float* target = devicePtr ? pixels : dDst;
+    e = hipMemcpyAsync(dW, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dSrc, pixels, bytes, devicePtr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        BloomParams bp { params->bloom_threshold, params->bloom_scale, k, params->bloom_gaussian, params->bloom_debug, dW };
+        e = launch_bloom(dSrc, target, width, height, bp, s);
+    }
+    if (e == hipSuccess && !devicePtr) e = hipMemcpyAsync(pixels, dDst, bytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) return hip_fail(e, "rt_bloom");
+    return RT_OK;
+}
+
+} // extern "C"

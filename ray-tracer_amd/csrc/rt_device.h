@@ -1,0 +1,637 @@
+// Device code of the render loop: ray/box and ray/primitive tests, stack traversal of the flattened
+// hierarchy, hit attributes, lights, Phong, cube map, and the iterative form of the reference's recursive
+// colour evaluation.  Included by rt_kernels.hip only.
+//
+// One lane owns one ray at a time (wave64; 64 rays in flight per wave).  The traversal stack lives in LDS,
+// laid out [entry][lane] so that lanes never collide on a bank whatever depth each of them is at.
+#pragma once
+#include "rt_amd.h"
+#include "rt_layout.h"
+
+namespace rt {
+
+// Per-light constants the reference recomputes at every hit (reference src/light.cpp:151-155,188-194);
+// they only depend on the light and the sampling tunables, so the host evaluates them once per frame with
+// the same fp32 operations.
+struct LightDev {
+    int32_t type;
+    float v[21];
+    float recA, recB;   // segment: sampleCountRec, segmentLengthRec; parallelogram: dirISamplesRec, dirJSamplesRec
+    int32_t nA, nB;     // trip counts of the reference's sample loops (its float loop bounds evaluated on the host)
+    float step[3];      // segment: sampleDistanceSegment
+    int32_t draws;      // rand() calls one evaluation of this light consumes
+};
+
+enum { MAX_LIGHTS = 16 };
+
+struct FrameParams {
+    SceneView scene;
+    quat camQ;
+    float camPos[3], camUp[3], camLeft[3];
+    float halfW, halfH;
+    int32_t width, height, rowBegin, rowEnd;
+    rt_features f;
+    rt_params p;
+    LightDev lights[MAX_LIGHTS]; // travels in the kernel argument block: read with scalar loads, no upload to order
+    int32_t nLights;
+    int32_t drawsPerHit; // rand() calls one computeLightContribution consumes
+    // Output.  One lane evaluates one (pixel, sample) pair.  With a single sample per pixel the colour goes
+    // straight to `out` (Screen order); otherwise to plane s of `samples` ([sample][row][x][rgb], rows in
+    // Screen order) and a resolve pass sums the planes in the reference's order.
+    float* out;
+    float* samples;
+    uint8_t* dofFlags;     // per pixel: 1 when the thin-lens samples take part (render.cpp:110)
+    int32_t sampleBegin, sampleEnd, samplesPerPixel;
+    unsigned long long* stats; // primary, shadow, bounce, probe, box, tri, overflow
+    int32_t countTests;
+};
+
+struct Counts {
+    uint32_t primary = 0, shadow = 0, bounce = 0, probe = 0, box = 0, tri = 0, overflow = 0;
+};
+
+struct RayD {
+    vec3 o, d;
+    // per-axis reciprocal and the two direction classes the slab test branches on (reference
+    // src/intersect.cpp:114-126); a function of the ray only, so computed once per ray
+    vec3 inv;
+    bool zx, zy, zz, px, py, pz;
+};
+
+__device__ __forceinline__ RayD make_ray(vec3 o, vec3 d)
+{
+    RayD r;
+    r.o = o;
+    r.d = d;
+    r.inv = make3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.zx = is_zero(d.x); r.zy = is_zero(d.y); r.zz = is_zero(d.z);
+    r.px = d.x > 0; r.py = d.y > 0; r.pz = d.z > 0;
+    return r;
+}
+
+// Ray/box test of reference src/intersect.cpp:111-140 without the final comparison against ray.t: returns
+// whether the box is entered at all and the parameter the reference would report (t_out when the origin is
+// inside).  The caller compares against its own bound.
+__device__ __forceinline__ bool box_entry(const RayD& r, const float* lo, const float* hi, float& tBox)
+{
+    float t0 = r.zx ? -FLT_MAX : ((r.px ? lo[0] : hi[0]) - r.o.x) * r.inv.x;
+    float t1 = r.zx ? FLT_MAX : ((r.px ? hi[0] : lo[0]) - r.o.x) * r.inv.x;
+    float t2 = r.zy ? -FLT_MAX : ((r.py ? lo[1] : hi[1]) - r.o.y) * r.inv.y;
+    float t3 = r.zy ? FLT_MAX : ((r.py ? hi[1] : lo[1]) - r.o.y) * r.inv.y;
+    float t4 = r.zz ? -FLT_MAX : ((r.pz ? lo[2] : hi[2]) - r.o.z) * r.inv.z;
+    float t5 = r.zz ? FLT_MAX : ((r.pz ? hi[2] : lo[2]) - r.o.z) * r.inv.z;
+    float tin = sel_max(sel_max(t0, t2), t4);
+    float tout = sel_min(sel_min(t1, t3), t5);
+    if (tin > tout || tout <= 0 || is_zero(tin)) return false;
+    tBox = tin < 0 ? tout : tin;
+    return true;
+}
+
+// Ray/triangle test of reference src/intersect.cpp:22-80 on a precomputed record.  `tmax` is the current
+// closest distance; returns true and the new distance when the triangle is accepted.  The rejections are
+// evaluated cheapest-first; each is a pure predicate, so the order does not change the outcome.
+__device__ __forceinline__ bool triangle_hit(const RayD& r, const PrimRec& p, float tmax, float& tHit)
+{
+    const vec3 n = load3(p.n);
+    const vec3 v0 = load3(p.v0);
+    const float dn = dot(n, r.d);
+    if (is_zero(dn)) return false;
+    const float D = dot(n, v0);
+    const float t = (D - dot(r.o, n)) / dn;
+    if (!(t > 0)) return false;
+    if (!(t < tmax)) return false;
+    const vec3 pt = r.o + r.d * t;
+    if (!is_zero(dot(n, pt - v0))) return false;
+    const vec3 v1 = load3(p.v1), v2 = load3(p.v2);
+    const float alpha = length(cross(pt - v2, v1 - v2)) * p.invArea;
+    const float beta = length(cross(pt - v2, v0 - v2)) * p.invArea;
+    const float gamma = length(cross(pt - v1, v0 - v1)) * p.invArea;
+    if (alpha < 0 || beta < 0 || alpha + beta > 1.0f || alpha + gamma > 1.0f || beta + gamma > 1.0f) return false;
+    tHit = t;
+    return true;
+}
+
+// LDS traversal stack of one lane.  Entry e of lane l sits at base[e * blockDim + l].
+struct Stack {
+    uint2* base;
+    uint32_t stride;
+    __device__ __forceinline__ void push(int sp, int32_t ref, float t) { base[uint32_t(sp) * stride] = make_uint2(uint32_t(ref), __float_as_uint(t)); }
+    __device__ __forceinline__ void pop(int sp, int32_t& ref, float& t) const
+    {
+        uint2 e = base[uint32_t(sp) * stride];
+        ref = int32_t(e.x);
+        t = __uint_as_float(e.y);
+    }
+};
+
+// Closest-hit (ANY = false) or any-hit (ANY = true) query, result-equivalent to the reference's recursive
+// traversal (reference src/bounding_volume_hierarchy.cpp:293-449, 529-547):
+//   - the whole query is rejected unless the root box is entered before the caller's bound `tmax`;
+//   - with PRUNE (neither recursive nor transparency enabled) a node is skipped when its box parameter
+//     exceeds the closest triangle distance found so far; without PRUNE every entered box is visited;
+//   - both children are tested against an unbounded ray; the one with the smaller box parameter is visited
+//     first, the right one on a tie;
+//   - a triangle is accepted when strictly closer than the current distance, so ties keep the first found.
+// Returns the slot of the accepted primitive (or -1) and updates tmax.  An any-hit query returns at the
+// first accepted triangle: the reference's boolean is the same because acceptance is what sets it.
+template <bool PRUNE, bool ANY, bool COUNT>
+__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt)
+{
+    if (S.numPrims == 0) return -1;
+    float tRoot;
+    if (COUNT) cnt.box++;
+    if (!box_entry(r, S.rootLo, S.rootHi, tRoot) || !(tRoot < tmax)) return -1;
+    int hit = -1;
+    int sp = 0;
+    int32_t cur = S.rootRef;
+    float curT = tRoot;
+    while (true) {
+        bool skip = false;
+        if (PRUNE) {
+            const float best = hit >= 0 ? tmax : FLT_MAX;
+            skip = curT > best;
+        }
+        if (!skip) {
+            if (cur >= 0) {
+                const NodeRec& nd = S.nodes[cur];
+                float tL, tR;
+                if (COUNT) cnt.box += 2;
+                bool vL = box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
+                bool vR = box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
+                const int32_t refL = nd.refL, refR = nd.refR;
+                if (vL && vR) {
+                    if (tL < tR) { st.push(sp++, refR, tR); cur = refL; curT = tL; }
+                    else { st.push(sp++, refL, tL); cur = refR; curT = tR; }
+                    continue;
+                }
+                if (vR) { cur = refR; curT = tR; continue; }
+                if (vL) { cur = refL; curT = tL; continue; }
+            } else {
+                int32_t slot = ~cur;
+                int32_t more;
+                do {
+                    const PrimRec& p = S.prims[slot];
+                    more = p.more;
+                    if (COUNT) cnt.tri++;
+                    float t;
+                    if (triangle_hit(r, p, tmax, t)) {
+                        tmax = t;
+                        hit = slot;
+                        if (ANY) return hit;
+                    }
+                    slot++;
+                } while (more > 0);
+            }
+        }
+        if (sp == 0) break;
+        st.pop(--sp, cur, curT);
+    }
+    return hit;
+}
+
+// Brute-force branch (reference src/bounding_volume_hierarchy.cpp:462-528): every triangle in mesh order.
+template <bool ANY, bool COUNT>
+__device__ int brute_force(const SceneView& S, const RayD& r, float& tmax, Counts& cnt)
+{
+    int hit = -1;
+    for (int i = 0; i < S.numPrims; i++) {
+        const int slot = int(S.primOrder[i]);
+        const PrimRec& p = S.prims[slot];
+        if (COUNT) cnt.tri++;
+        float t;
+        if (triangle_hit(r, p, tmax, t)) {
+            tmax = t;
+            hit = slot;
+            if (ANY) return hit;
+        }
+    }
+    return hit;
+}
+
+template <bool PRUNE, bool ANY, bool COUNT>
+__device__ __forceinline__ int intersect(const FrameParams& P, const RayD& r, float& tmax, Stack st, Counts& cnt)
+{
+    if (!P.f.accel_structure) return brute_force<ANY, COUNT>(P.scene, r, tmax, cnt);
+    return traverse<PRUNE, ANY, COUNT>(P.scene, r, tmax, st, cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hit attributes
+// ---------------------------------------------------------------------------------------------------
+struct Surface {
+    vec3 normal;   // HitInfo::normal
+    vec3 bary;     // HitInfo::barycentricCoord
+    vec3 kd, ks;
+    float shininess, transparency;
+};
+
+__device__ __forceinline__ vec3 texel_u8(const uint8_t* texels, const ImageRec& im, int idx)
+{
+    const int n = im.width * im.height;
+    idx = idx < 0 ? 0 : (idx >= n ? n - 1 : idx); // the reference reads out of bounds here; clamp instead
+    const uint8_t* px = texels + im.offset + size_t(idx) * 3;
+    return make3(float(px[0]) / 255.0f, float(px[1]) / 255.0f, float(px[2]) / 255.0f);
+}
+
+// reference src/texture.cpp:5-17 (nearest texel, wrap by fmod; the intermediates are double there)
+__device__ __forceinline__ vec3 acquire_texel(const uint8_t* texels, const ImageRec& im, float u, float v)
+{
+    const float i = float(fmod(round(double(u * float(im.width)) - 0.5), double(im.width)));
+    const float j = float(fmod(round(double((1 - v) * float(im.height)) - 0.5), double(im.height)));
+    return texel_u8(texels, im, int(j * float(im.width) + i));
+}
+
+// reference src/interpolate.cpp:4-11
+__device__ __forceinline__ vec3 barycentric(vec3 v0, vec3 v1, vec3 v2, vec3 p)
+{
+    const float totalArea = length(cross(v0 - v2, v1 - v2)) / 2;
+    const float alpha = length(cross(p - v2, v1 - v2)) / (2 * totalArea);
+    const float beta = length(cross(p - v2, v0 - v2)) / (2 * totalArea);
+    const float gamma = length(cross(p - v1, v0 - v1)) / (2 * totalArea);
+    return make3(alpha, beta, gamma);
+}
+
+// What the reference leaves in HitInfo after an accepted triangle (intersect.cpp:74-78 and
+// bounding_volume_hierarchy.cpp:351-396): geometric normal, barycentrics, material, texel, and the
+// interpolated normal.  Only the final hit's values survive, so they are computed once, afterwards.
+__device__ __forceinline__ Surface surface_at(const FrameParams& P, const RayD& r, float t, int slot)
+{
+    const SceneView& S = P.scene;
+    const PrimRec& p = S.prims[slot];
+    Surface s;
+    const vec3 v0 = load3(p.v0), v1 = load3(p.v1), v2 = load3(p.v2);
+    const vec3 point = r.o + r.d * t;
+    s.normal = load3(p.n);
+    s.bary = barycentric(v0, v1, v2, point);
+    const MaterialRec& m = S.mats[p.mesh];
+    s.kd = load3(m.kd);
+    s.ks = load3(m.ks);
+    s.shininess = m.shininess;
+    s.transparency = m.transparency;
+    if ((P.f.texture_mapping && m.texture >= 0) || P.f.normal_interp) {
+        const AttrRec& a = S.attrs[slot];
+        if (P.f.texture_mapping && m.texture >= 0) {
+            const float tu = a.uv0[0] * s.bary.x + a.uv1[0] * s.bary.y + a.uv2[0] * s.bary.z; // interpolate.cpp:20-28
+            const float tv = a.uv0[1] * s.bary.x + a.uv1[1] * s.bary.y + a.uv2[1] * s.bary.z;
+            s.kd = acquire_texel(S.texels, S.textures[m.texture], tu, tv);
+        }
+        if (P.f.normal_interp) // interpolate.cpp:13-18
+            s.normal = normalize(s.bary.x * load3(a.n0) + s.bary.y * load3(a.n1) + s.bary.z * load3(a.n2));
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Cube map, reference src/environment_mapping.cpp:9-49
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ vec3 skybox_color(const SceneView& S, vec3 dir)
+{
+    if (!S.hasSkybox) return splat3(0.0f);
+    const vec3 v = normalize(dir);
+    const float ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z);
+    float maxA, ut, vt;
+    int face;
+    if (ax >= ay && ax >= az) {
+        maxA = 2 * ax;
+        ut = (v.x >= 0) ? -v.z : v.z;
+        vt = -v.y;
+        face = 1 - int(v.x < 0); // the x faces are swapped
+    } else if (ay >= az) {
+        maxA = 2 * ay;
+        ut = v.x;
+        vt = (v.y >= 0) ? v.z : -v.z;
+        face = int(v.y < 0) + 2;
+    } else {
+        maxA = 2 * az;
+        ut = (v.z >= 0) ? v.x : -v.x;
+        vt = -v.y;
+        face = int(v.z < 0) + 4;
+    }
+    const float tu = float(double(-(ut / maxA)) + 0.5);
+    const float tv = float(double(-(vt / maxA)) + 0.5);
+    const ImageRec& im = S.skybox[face];
+    const int i = int(tu * float(im.width));
+    float fj = (1.0f - tv) * float(im.height);
+    const float hiJ = float(im.height) - 1.0f;
+    fj = fj < 0.0f ? 0.0f : (hiJ < fj ? hiJ : fj); // std::clamp
+    const int j = int(fj);
+    return texel_u8(S.texels, im, j * im.width + i);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Lights and shading
+// ---------------------------------------------------------------------------------------------------
+struct Rng {
+    uint32_t pixelKey, sample, randCounter, glossCall;
+    __device__ __forceinline__ int rand31() { return int(rng_u32(pixelKey, sample, RNG_STREAM_RAND, randCounter++) >> 1); }
+    __device__ __forceinline__ double gauss(uint32_t idx) const
+    {
+        const uint32_t a = rng_u32(pixelKey, sample, RNG_STREAM_GLOSS, 2u * idx);
+        const uint32_t b = rng_u32(pixelKey, sample, RNG_STREAM_GLOSS, 2u * idx + 1u);
+        return sqrt(-2.0 * log(rng_unit(a))) * cos(6.283185307179586476925 * rng_unit(b));
+    }
+};
+
+// Phong term, reference src/shading.cpp:6-39 (the exponent goes through double pow there)
+__device__ __forceinline__ vec3 phong(vec3 lightPos, vec3 lightColor, const RayD& r, float t, const Surface& s)
+{
+    const vec3 P = r.o + (r.d * t);
+    const vec3 N = normalize(s.normal);
+    const vec3 L = normalize(lightPos - P);
+    const float nl = dot(N, L);
+    const float lambertian = nl > 0 ? nl : 0;
+    const vec3 diffuse = lightColor * s.kd * lambertian;
+    float specular = 0.0f;
+    if (lambertian > 0) {
+        const vec3 R = reflect(L, N);
+        const vec3 V = normalize(-r.o + P);
+        const float rv = dot(R, V);
+        const float specAngle = rv > 0 ? rv : 0;
+        specular = float(pow(double(specAngle), double(s.shininess)));
+    }
+    return lightColor * s.ks * specular + diffuse;
+}
+
+// reference src/light.cpp:68-89
+template <bool PRUNE, bool COUNT>
+__device__ __forceinline__ float visibility(const FrameParams& P, vec3 samplePos, const RayD& r, float t, Stack st, Counts& cnt)
+{
+    const float epsilon = 0.00001f;
+    const vec3 origin = r.o + (1 - epsilon) * t * r.d;
+    const RayD shadow = make_ray(origin, samplePos - origin);
+    float tmax = 1.0f;
+    cnt.shadow++;
+    return intersect<PRUNE, true, COUNT>(P, shadow, tmax, st, cnt) >= 0 ? 0.0f : 1.0f;
+}
+
+// reference src/light.cpp:124-220, with the two samplers (:22-64) inlined.  All light types run through one
+// sample loop so the kernel holds a single copy of the shadow-ray traversal and of the Phong term.
+template <bool PRUNE, bool COUNT>
+__device__ vec3 light_contribution(const FrameParams& P, const RayD& r, float t, const Surface& s, Rng& rng, Stack st, Counts& cnt)
+{
+    vec3 shading = splat3(0.0f);
+    for (int li = 0; li < P.nLights; li++) {
+        const LightDev& L = P.lights[li];
+        const int type = L.type;
+        if (type != RT_LIGHT_POINT && !(P.f.soft_shadow || P.f.shading)) continue;
+        const bool shadowed = type == RT_LIGHT_POINT ? P.f.hard_shadow != 0 : P.f.soft_shadow != 0;
+        const int nB = L.nB, total = L.nA * nB;
+        for (int k = 0; k < total; k++) {
+            vec3 position, color;
+            if (type == RT_LIGHT_POINT) {
+                position = load3(L.v);
+                color = load3(L.v + 3);
+            } else if (type == RT_LIGHT_SEGMENT) {
+                const vec3 e0 = load3(L.v), e1 = load3(L.v + 3), c0 = load3(L.v + 6), c1 = load3(L.v + 9);
+                const float randomUniform = float(rng.rand31() % 50) / 50.0f;
+                const vec3 randomAddition = load3(L.step) * randomUniform;
+                const float alpha = float(k) * L.recA;
+                position = (e0 * (1 - alpha) + e1 * alpha) + randomAddition;
+                float p0 = 0.5f, p1 = 0.5f;
+                if (L.recB != 0) {
+                    p1 = length(position - e0) * L.recB;
+                    p0 = 1 - p1;
+                }
+                color = p0 * c0 + p1 * c1;
+            } else {
+                const int i = k / nB, j = k - i * nB;
+                const vec3 v0 = load3(L.v), e01 = load3(L.v + 3), e02 = load3(L.v + 6);
+                const vec3 c0 = load3(L.v + 9), c1 = load3(L.v + 12), c2 = load3(L.v + 15), c3 = load3(L.v + 18);
+                const float ri = float(rng.rand31() % 50) / 50.0f + float(i);
+                const float rj = float(rng.rand31() % 50) / 50.0f + float(j);
+                const float x = ri * L.recA, y = rj * L.recB;
+                position = (v0 + e01 * x) + e02 * y;
+                color = (1 - y) * (x * c1 + (1 - x) * c0) + y * (x * c3 + (1 - x) * c2);
+            }
+            const float lighted = shadowed ? visibility<PRUNE, COUNT>(P, position, r, t, st, cnt) : 1.0f;
+            vec3 shade = P.f.shading ? phong(position, color, r, t, s) : s.kd;
+            if (type == RT_LIGHT_SEGMENT) shade = shade * L.recA;
+            else if (type == RT_LIGHT_PARALLELOGRAM) shade = shade * L.recA * L.recB;
+            shading = shading + shade * lighted;
+        }
+    }
+    return shading;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Colour of one ray: the reference's recursion (src/render.cpp:18-80) unrolled into a loop with an
+// explicit frame stack, so results combine in exactly the order the recursion would.
+//   MIRROR frame:  result = ks * child                              (render.cpp:61)
+//   BLEND  frame:  result = a * Lo + (1 - a) * child                (render.cpp:43)
+//   GLOSSY frame:  result = ks * (sum of children) / filterSize     (render.cpp:53-59), children generated
+//                  one after the other by perturbing the reflection ray (src/gloss.cpp:14-51)
+// ---------------------------------------------------------------------------------------------------
+enum { FRAME_MIRROR = 0, FRAME_BLEND = 1, FRAME_GLOSSY = 2 };
+enum { MAX_SPECULAR_DEPTH = 8, MAX_BLEND_DEPTH = 24, MAX_FRAMES = MAX_SPECULAR_DEPTH + MAX_BLEND_DEPTH };
+
+struct Frame {
+    float a;  // BLEND: transparency
+    vec3 c;   // MIRROR/GLOSSY: ks; BLEND: Lo
+    int32_t kind;
+};
+
+struct GlossyFrame {
+    vec3 origin, dir, u, v, normal, sum;
+    float side, offset;
+    int32_t next, call, depth;
+};
+
+template <bool PRUNE, bool GLOSSY, bool COUNT>
+__device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, Rng& rng, Stack st, Counts& cnt, float& firstT)
+{
+    bool first = true;
+    Frame frames[MAX_FRAMES];
+    GlossyFrame gframes[GLOSSY ? MAX_SPECULAR_DEPTH : 1];
+    int nFrames = 0, nGlossy = 0, blendDepth = 0;
+    int depth = P.p.ray_depth; // bounce budget of the ray currently being traced / whose result is held
+    vec3 result = splat3(0.0f);
+    RayD r = make_ray(origin, direction);
+    enum { TRACE, SPAWN, RETURN } state = TRACE;
+    while (true) {
+        if (state == TRACE) {
+            float t = FLT_MAX;
+            const int slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
+            state = RETURN;
+            if (first) {
+                firstT = t;
+                first = false;
+            }
+            if (slot < 0) {
+                result = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
+                continue;
+            }
+            const Surface s = surface_at(P, r, t, slot);
+            const bool reflMap = P.f.environment_mapping && P.p.enabled_refl_map;
+            const bool blend = !reflMap && P.f.transparency && s.transparency != 1.0f;
+            const bool specular = !reflMap && !blend && (P.f.recursive || P.f.glossy) && depth > 0 && (s.ks.x != 0 || s.ks.y != 0 || s.ks.z != 0);
+            // The reference evaluates the direct lighting at every hit and then drops it on the mirror /
+            // glossy / reflection-map branches (render.cpp:25,27-34,48-63).  Those branches skip the work
+            // here but still consume the same random draws, so later draws keep their indices.
+            vec3 Lo = splat3(0.0f);
+            if (reflMap || specular) rng.randCounter += uint32_t(P.drawsPerHit);
+            else Lo = light_contribution<PRUNE, COUNT>(P, r, t, s, rng, st, cnt);
+            if (reflMap) {
+                result = skybox_color(P.scene, r.d);
+            } else if (blend) {
+                if (blendDepth >= P.p.max_transparency_depth) {
+                    cnt.overflow++;
+                    result = Lo;
+                } else {
+                    Frame& f = frames[nFrames++];
+                    f.kind = FRAME_BLEND;
+                    f.a = s.transparency;
+                    f.c = Lo;
+                    blendDepth++;
+                    cnt.bounce++;
+                    r = make_ray((t + 0.000001f) * r.d + r.o, r.d);
+                    state = TRACE;
+                }
+            } else if (specular) {
+                // computeReflectionRay, reference src/shading.cpp:42-51
+                const float epsilon = 0.00001f;
+                const vec3 rd = r.d - (2 * dot(r.d, s.normal)) * s.normal;
+                const vec3 ro = t * r.d * (1 - epsilon) + r.o;
+                Frame& f = frames[nFrames++];
+                f.c = s.ks;
+                f.a = 0.0f;
+                if (GLOSSY && P.f.glossy) {
+                    // basis and footprint of getRaySamples, reference src/gloss.cpp:16-43
+                    f.kind = FRAME_GLOSSY;
+                    GlossyFrame& g = gframes[nGlossy++];
+                    const vec3 w = normalize(rd);
+                    const float awx = fabsf(w.x), awy = fabsf(w.y), awz = fabsf(w.z);
+                    const int minTerm = (awx <= awy && awx <= awz) ? 0 : ((awy <= awx && awy <= awz) ? 1 : 2);
+                    vec3 tt = w;
+                    if (minTerm == 0) tt.x = 1; else if (minTerm == 1) tt.y = 1; else tt.z = 1;
+                    g.u = normalize(cross(tt, w));
+                    g.v = cross(w, g.u);
+                    g.side = P.p.glossy_sigma / (s.shininess * 3.0f);
+                    g.offset = -g.side / 2.0f;
+                    g.origin = ro;
+                    g.dir = rd;
+                    g.normal = s.normal;
+                    g.sum = splat3(0.0f);
+                    g.next = 0;
+                    g.call = int32_t(rng.glossCall++);
+                    g.depth = depth;
+                    state = SPAWN;
+                } else {
+                    f.kind = FRAME_MIRROR;
+                    depth--;
+                    cnt.bounce++;
+                    r = make_ray(ro, rd);
+                    state = TRACE;
+                }
+            } else {
+                result = Lo;
+            }
+        } else if (GLOSSY && state == SPAWN) {
+            // next surviving sample of the glossy frame on top (reference src/gloss.cpp:44-49), or its total
+            GlossyFrame& g = gframes[nGlossy - 1];
+            state = RETURN;
+            while (g.next < P.p.glossy_filter_size) {
+                const uint32_t k = (uint32_t(g.call) * uint32_t(P.p.glossy_filter_size) + uint32_t(g.next)) * 2u;
+                g.next++;
+                const double n0 = rng.gauss(k), n1 = rng.gauss(k + 1u);
+                const vec3 rp = (g.dir + float(double(g.offset) + n0 * double(g.side)) * g.u) + float(double(g.offset) + n1 * double(g.side)) * g.v;
+                if (dot(rp, g.normal) > 0) {
+                    depth = g.depth - 1;
+                    cnt.bounce++;
+                    r = make_ray(g.origin, normalize(rp));
+                    state = TRACE;
+                    break;
+                }
+            }
+            if (state == RETURN) {
+                const Frame& f = frames[--nFrames];
+                result = f.c * g.sum / float(P.p.glossy_filter_size);
+                depth = g.depth;
+                nGlossy--;
+            }
+        } else {
+            // RETURN: hand `result` to the innermost pending frame
+            if (nFrames == 0) return result;
+            const Frame& f = frames[nFrames - 1];
+            if (f.kind == FRAME_MIRROR) {
+                result = f.c * result;
+                depth++;
+                nFrames--;
+            } else if (f.kind == FRAME_BLEND) {
+                result = f.a * f.c + (1.0f - f.a) * result;
+                blendDepth--;
+                nFrames--;
+            } else if (GLOSSY) {
+                GlossyFrame& g = gframes[nGlossy - 1];
+                g.sum = g.sum + result;
+                state = SPAWN;
+            } else {
+                nFrames--;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One pixel: reference src/render.cpp:93-122 with calculateColor (src/multipleRays.cpp:15-54) and
+// getEyeFrame (src/dof.cpp:21-51) inlined.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void camera_ray(const FrameParams& P, float px, float py, vec3& o, vec3& d)
+{
+    // reference framework/src/trackball.cpp:101-110
+    const vec3 c = normalize(make3(-px * P.halfW, py * P.halfH, 1.0f));
+    o = load3(P.camPos);
+    d = rotate(P.camQ, c);
+}
+
+// Colour of sample `sidx` of pixel (x, y):
+//   supersampling on  -> sample (i, j) = (sidx / n, sidx % n) of calculateColor's n x n loop;
+//   depth of field on -> sample 0 is the centre ray (whose first hit distance doubles as the reference's
+//                        probe query, render.cpp:106-110: same ray, same traversal), samples 1.. the lens rays;
+//   otherwise         -> the single camera ray.
+template <bool PRUNE, bool GLOSSY, bool COUNT>
+__device__ vec3 render_sample(const FrameParams& P, int x, int y, int sidx, Stack st, Counts& cnt, bool& dofFlag)
+{
+    Rng rng;
+    rng.pixelKey = rng_pixel_key(P.p.seed, uint32_t(y * P.width + x));
+    rng.glossCall = 0;
+    rng.sample = uint32_t(sidx);
+    const float W = float(P.width), H = float(P.height);
+    vec3 o, d;
+    if (P.f.multiple_rays) {
+        const int n = P.p.ray_multiplier;
+        const int i = sidx / n, j = sidx - i * n;
+        rng.randCounter = 0;
+        const float randomx = float(rng.rand31() % 100) / 100.0f;
+        const float randomy = float(rng.rand31() % 100) / 100.0f;
+        const float px = (float(x) + (float(i) / float(n) + randomx)) / W * 2.0f - 1.0f;
+        const float py = (float(y) + (float(j) / float(n) + randomy)) / H * 2.0f - 1.0f;
+        camera_ray(P, px, py, o, d);
+    } else {
+        const float px = float(x) / W * 2.0f - 1.0f;
+        const float py = float(y) / H * 2.0f - 1.0f;
+        camera_ray(P, px, py, o, d);
+        rng.randCounter = 2; // indices 0 and 1 belong to the pixel jitter
+        if (P.f.depth_of_field && sidx > 0) {
+            // getEyeFrame, reference src/dof.cpp:21-51
+            const int k = sidx - 1;
+            const vec3 w = normalize(d);
+            const vec3 up = load3(P.camUp), left = load3(P.camLeft);
+            const float side = P.p.dof_f / (P.p.dof_aperture * 6.0f);
+            const float offset = -side / 2.0f;
+            const vec3 focus = o + w * P.p.dof_f;
+            const double u0 = rng_unit(rng_u32(rng.pixelKey, 0, RNG_STREAM_DOF, uint32_t(2 * k)));
+            const double u1 = rng_unit(rng_u32(rng.pixelKey, 0, RNG_STREAM_DOF, uint32_t(2 * k + 1)));
+            const vec3 eye = (o + float(double(offset) + u0 * double(side)) * up) + float(double(offset) + u1 * double(side)) * left;
+            d = normalize(focus - eye);
+            o = eye;
+        }
+    }
+    cnt.primary++;
+    const float dlen = length(d);
+    float firstT;
+    const vec3 color = final_color<PRUNE, GLOSSY, COUNT>(P, o, d, rng, st, cnt, firstT);
+    dofFlag = firstT != FLT_MAX && fabsf(P.p.dof_f - dlen * firstT) > P.p.dof;
+    return color;
+}
+
+} // namespace rt

@@ -1,0 +1,28 @@
+// Launch wrappers around the HIP kernels (defined in rt_kernels.hip); called by the C ABI in rt_api.cpp.
+#pragma once
+#include "rt_device.h"
+
+#include <hip/hip_runtime.h>
+
+namespace rt {
+
+enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_COUNT };
+
+// Renders rows [P.rowBegin, P.rowEnd) into P.out.  Returns the HIP status of the launch.
+hipError_t launch_render(const FrameParams& P, hipStream_t stream);
+
+// n closest-hit queries; rays/hits are device pointers.
+hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n, rt_hit* hits, hipStream_t stream);
+
+// out[i*nSamples+s] = visibility of samples[s] from hit point i (rays carry the hit distance in t).
+hipError_t launch_visibility(const FrameParams& P, const rt_ray* rays, uint64_t n, const float* samples, int nSamples, uint8_t* out, hipStream_t stream);
+
+struct BloomParams {
+    float threshold, scale;
+    int32_t size, gaussian, debug;
+    const float* weights; // (2*size+1)^2 filter weights, row j column i at [j*(2*size+1)+i] (device memory)
+};
+// dst = src + scale * filtered(mask(src)) (or just the filtered term in debug mode); src and dst differ.
+hipError_t launch_bloom(const float* src, float* dst, int width, int height, const BloomParams& bp, hipStream_t stream);
+
+} // namespace rt

@@ -1,0 +1,258 @@
+// HIP kernels of librt_amd for gfx950 (MI355X).  Compiled with -ffp-contract=off: the ray/box and
+// ray/triangle decisions must round exactly like the reference's scalar fp32 code.
+#include "rt_kernels.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int BLOCK = 256;  // 4 waves; each wave renders an 8x8 pixel tile, the block a 16x16 tile
+constexpr int TILE = 16;
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* stats)
+{
+    if (!stats) return;
+    const uint32_t vals[STAT_COUNT] = { c.primary, c.shadow, c.bounce, c.probe, c.box, c.tri, c.overflow };
+#pragma unroll
+    for (int i = 0; i < STAT_COUNT; i++) {
+        const uint32_t s = wave_sum(vals[i]);
+        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
+    }
+}
+
+// Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  Renumber them so that every XCD
+// walks one contiguous run of tiles (one band of the frame) and its L2 keeps the part of the hierarchy
+// that band touches.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t n)
+{
+    const uint32_t q = n / 8, rem = n % 8, xcd = b % 8, idx = b / 8;
+    const uint32_t base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return base + idx;
+}
+
+// One lane = one (pixel, sample).  A wave covers an 8x8 pixel tile at one sample index, a block a 16x16
+// tile; consecutive logical blocks are the samples of one tile, then the next tile.
+template <bool PRUNE, bool GLOSSY, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) k_render(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    const int tid = int(threadIdx.x);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tilesX = (P.width + TILE - 1) / TILE;
+    const int nS = P.sampleEnd - P.sampleBegin;
+    const uint32_t logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tile = int(logical) / nS;
+    const int sidx = P.sampleBegin + int(logical) % nS;
+    const int bx = tile % tilesX, by = tile / tilesX;
+    const int x = bx * TILE + (wave & 1) * 8 + (lane & 7);
+    const int y = P.rowBegin + by * TILE + (wave >> 1) * 8 + (lane >> 3);
+    Stack st { lds_stack + tid, uint32_t(BLOCK) };
+    Counts cnt;
+    if (x < P.width && y < P.rowEnd) {
+        const size_t pix = size_t(P.rowEnd - 1 - y) * size_t(P.width) + size_t(x);
+        bool live = true;
+        if (P.f.depth_of_field && sidx > 0) live = P.dofFlags[pix] != 0;
+        if (live) {
+            bool dofFlag = false;
+            const vec3 c = render_sample<PRUNE, GLOSSY, COUNT>(P, x, y, sidx, st, cnt, dofFlag);
+            float* o;
+            if (P.samplesPerPixel == 1) o = P.out + pix * 3;
+            else o = P.samples + (size_t(sidx) * size_t(P.rowEnd - P.rowBegin) * size_t(P.width) + pix) * 3;
+            o[0] = c.x;
+            o[1] = c.y;
+            o[2] = c.z;
+            if (P.f.depth_of_field && sidx == 0) P.dofFlags[pix] = dofFlag ? 1 : 0;
+        }
+    }
+    flush_counts(cnt, P.stats);
+}
+
+// Sums the sample planes of each pixel in sample order and divides like the reference does:
+// supersampling: sum / float(n*n) (multipleRays.cpp:50); depth of field: (centre + lens rays) / (n + 1) when
+// the pixel's flag is set, else the centre ray alone (render.cpp:109-118).
+__global__ void __launch_bounds__(BLOCK) k_resolve(const FrameParams P)
+{
+    const size_t nPix = size_t(P.rowEnd - P.rowBegin) * size_t(P.width);
+    const size_t pix = size_t(blockIdx.x) * BLOCK + threadIdx.x;
+    if (pix >= nPix) return;
+    const int S = P.samplesPerPixel;
+    vec3 color = load3(P.samples + pix * 3);
+    if (P.f.multiple_rays) {
+        color = splat3(0.0f) + color;
+        for (int s = 1; s < S; s++) color = color + load3(P.samples + (size_t(s) * nPix + pix) * 3);
+        color = color / float(S);
+    } else if (P.dofFlags[pix]) {
+        for (int s = 1; s < S; s++) color = color + load3(P.samples + (size_t(s) * nPix + pix) * 3);
+        color = color / float(S);
+    }
+    P.out[pix * 3] = color.x;
+    P.out[pix * 3 + 1] = color.y;
+    P.out[pix * 3 + 2] = color.z;
+}
+
+template <bool PRUNE>
+__global__ void __launch_bounds__(BLOCK) k_intersect(const FrameParams P, const rt_ray* __restrict__ rays, uint64_t n, rt_hit* __restrict__ hits)
+{
+    extern __shared__ uint2 lds_stack[];
+    const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    Stack st { lds_stack + threadIdx.x, uint32_t(BLOCK) };
+    Counts cnt;
+    if (i < n) {
+        const rt_ray ray = rays[i];
+        const RayD r = make_ray(load3(ray.origin), load3(ray.direction));
+        float t = ray.t;
+        const int slot = intersect<PRUNE, false, true>(P, r, t, st, cnt);
+        rt_hit h;
+        h.hit = slot >= 0;
+        h.t = t;
+        h.mesh = -1;
+        h.triangle = -1;
+        h.normal[0] = h.normal[1] = h.normal[2] = 0.0f;
+        h.bary[0] = h.bary[1] = h.bary[2] = 0.0f;
+        h.kd[0] = h.kd[1] = h.kd[2] = 0.0f;
+        if (slot >= 0) {
+            const PrimRec& p = P.scene.prims[slot];
+            const Surface s = surface_at(P, r, t, slot);
+            h.mesh = p.mesh;
+            h.triangle = p.prim;
+            h.normal[0] = s.normal.x; h.normal[1] = s.normal.y; h.normal[2] = s.normal.z;
+            h.bary[0] = s.bary.x; h.bary[1] = s.bary.y; h.bary[2] = s.bary.z;
+            h.kd[0] = s.kd.x; h.kd[1] = s.kd.y; h.kd[2] = s.kd.z;
+        }
+        hits[i] = h;
+    }
+    flush_counts(cnt, P.stats);
+}
+
+template <bool PRUNE>
+__global__ void __launch_bounds__(BLOCK) k_visibility(const FrameParams P, const rt_ray* __restrict__ rays, uint64_t n, const float* __restrict__ samples, int nSamples, uint8_t* __restrict__ out)
+{
+    extern __shared__ uint2 lds_stack[];
+    const uint64_t i = uint64_t(blockIdx.x) * BLOCK + threadIdx.x;
+    Stack st { lds_stack + threadIdx.x, uint32_t(BLOCK) };
+    Counts cnt;
+    if (i < n * uint64_t(nSamples)) {
+        const uint64_t ri = i / uint64_t(nSamples);
+        const int si = int(i % uint64_t(nSamples));
+        const rt_ray ray = rays[ri];
+        const RayD r = make_ray(load3(ray.origin), load3(ray.direction));
+        out[i] = visibility<PRUNE, false>(P, load3(samples + 3 * si), r, ray.t, st, cnt) != 0.0f ? 1 : 0;
+    }
+}
+
+// Bloom, reference src/bloom.cpp:52-114: thresholded copy of the frame filtered with a (2k+1)^2 kernel whose
+// vertical taps are strided by HEIGHT (bloom.cpp:66), bounds-checked on the flat index and on the column of
+// the centre pixel only.  Taps are accumulated column-offset-major like the reference's loops.
+__global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, float* __restrict__ dst, int width, int height, BloomParams bp)
+{
+    const long n = long(width) * long(height);
+    const long idx = long(blockIdx.x) * BLOCK + threadIdx.x;
+    if (idx >= n) return;
+    const int k = bp.size, size = 2 * k + 1;
+    const float boxDiv = float(size * size);
+    const int col = int(idx % width);
+    vec3 avg = splat3(0.0f);
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            const int dx = i - k;
+            const long at = idx + long(j - k) * height + dx;
+            const int x = dx + col;
+            if (x >= 0 && x < width && at >= 0 && at < n) {
+                vec3 c = load3(src + at * 3);
+                if (!(c.x > bp.threshold || c.y > bp.threshold || c.z > bp.threshold)) c = splat3(0.0f);
+                if (bp.gaussian) avg = avg + c * bp.weights[j * size + i];
+                else avg = avg + c / boxDiv;
+            }
+        }
+    const vec3 add = avg * bp.scale;
+    const vec3 base = bp.debug ? splat3(0.0f) : load3(src + idx * 3);
+    const vec3 o = bp.debug ? add : base + add;
+    dst[idx * 3] = o.x;
+    dst[idx * 3 + 1] = o.y;
+    dst[idx * 3 + 2] = o.z;
+}
+
+size_t stack_bytes(const FrameParams& P)
+{
+    int depth = P.scene.stackDepth < 1 ? 1 : P.scene.stackDepth;
+    return size_t(BLOCK) * size_t(depth) * sizeof(uint2);
+}
+
+template <bool PRUNE, bool GLOSSY>
+hipError_t launch_render_t(const FrameParams& P, dim3 grid, size_t lds, hipStream_t stream)
+{
+    if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true>), grid, dim3(BLOCK), lds, stream, P);
+    else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false>), grid, dim3(BLOCK), lds, stream, P);
+    return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_render(const FrameParams& Pin, hipStream_t stream)
+{
+    FrameParams P = Pin;
+    const int rows = P.rowEnd - P.rowBegin;
+    if (rows <= 0 || P.width <= 0) return hipSuccess;
+    const uint32_t tiles = uint32_t((P.width + TILE - 1) / TILE) * uint32_t((rows + TILE - 1) / TILE);
+    const size_t lds = stack_bytes(P);
+    const bool prune = !P.f.recursive && !P.f.transparency;
+    const bool glossy = P.f.glossy != 0;
+    auto pass = [&](int sBegin, int sEnd) -> hipError_t {
+        P.sampleBegin = sBegin;
+        P.sampleEnd = sEnd;
+        const dim3 grid(tiles * uint32_t(sEnd - sBegin));
+        if (prune) return glossy ? launch_render_t<true, true>(P, grid, lds, stream) : launch_render_t<true, false>(P, grid, lds, stream);
+        return glossy ? launch_render_t<false, true>(P, grid, lds, stream) : launch_render_t<false, false>(P, grid, lds, stream);
+    };
+    hipError_t e;
+    if (P.f.depth_of_field && !P.f.multiple_rays && P.samplesPerPixel > 1) {
+        // the centre rays decide per pixel whether the lens rays are traced at all
+        if ((e = pass(0, 1)) != hipSuccess) return e;
+        if ((e = pass(1, P.samplesPerPixel)) != hipSuccess) return e;
+    } else {
+        if ((e = pass(0, P.samplesPerPixel)) != hipSuccess) return e;
+    }
+    if (P.samplesPerPixel > 1) {
+        const size_t nPix = size_t(rows) * size_t(P.width);
+        hipLaunchKernelGGL(k_resolve, dim3(uint32_t((nPix + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, P);
+        return hipGetLastError();
+    }
+    return hipSuccess;
+}
+
+hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n, rt_hit* hits, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const dim3 grid(uint32_t((n + BLOCK - 1) / BLOCK));
+    const size_t lds = stack_bytes(P);
+    if (!P.f.recursive && !P.f.transparency) hipLaunchKernelGGL(k_intersect<true>, grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+    else hipLaunchKernelGGL(k_intersect<false>, grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+    return hipGetLastError();
+}
+
+hipError_t launch_visibility(const FrameParams& P, const rt_ray* rays, uint64_t n, const float* samples, int nSamples, uint8_t* out, hipStream_t stream)
+{
+    const uint64_t total = n * uint64_t(nSamples);
+    if (total == 0) return hipSuccess;
+    const dim3 grid(uint32_t((total + BLOCK - 1) / BLOCK));
+    const size_t lds = stack_bytes(P);
+    if (!P.f.recursive && !P.f.transparency) hipLaunchKernelGGL(k_visibility<true>, grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+    else hipLaunchKernelGGL(k_visibility<false>, grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bloom(const float* src, float* dst, int width, int height, const BloomParams& bp, hipStream_t stream)
+{
+    const long n = long(width) * long(height);
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bloom, dim3(uint32_t((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, src, dst, width, height, bp);
+    return hipGetLastError();
+}
+
+} // namespace rt
