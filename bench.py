@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the render loop on MI355X.
+
+A step is one full frame of the headline workload (BASELINE.json: "dragon.obj 1080p 16spp soft shadows"):
+dragon-class mesh (data/dragon.obj is absent from the reference checkout, so a fixed-seed 81,920-triangle
+stand-in is synthesised, see ray-tracer_amd/synth.py), 1920x1080, the reference's default camera, Phong
+shading + parallelogram-light soft shadows (4 x 4 = 16 light samples per hit), 16 samples per pixel
+(ray_multiplier 4), BVH on.  Scene, hierarchy and textures are resident in HBM before the timed region; the
+frame is rendered into device memory.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is split into interleaved blocks of
+16 rows, every rank renders its blocks from its own replica of the scene, and the blocks are gathered on
+rank 0 over RCCL inside the timed region.  Total work is fixed, so scaling is "strong".
+
+Rank 0 prints one JSON line.  `value` is rays traced per second over the whole job (a ray = one closest-hit
+or any-hit query against the hierarchy: primary, shadow, bounce), in Mrays/s.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+ROW_BLOCK = 16
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak
+CAMERA = dict(fov_deg=50.0, distance=3.0, look_at=(0.0, 0.0, 0.0), rot_deg=(20.0, 20.0, 0.0))  # reference src/config.h:16-21
+
+
+def algorithmic_bytes(stats, pixels):
+    """28 B ray in + 16 B hit out per query, 32 B per ray/box test (24 B box + 8 B child reference), 36 B per
+    ray/triangle test (nine floats), 12 B per pixel written."""
+    rays = stats.primary_rays + stats.shadow_rays + stats.bounce_rays + stats.probe_rays
+    return 44 * rays + 32 * stats.box_tests + 36 * stats.triangle_tests + 12 * pixels
+
+
+def algorithmic_flops(stats):
+    """27 per ray/box test, 150 per ray/triangle test (sqrt and divide counted as one each), 60 + one pow per
+    shaded light sample."""
+    return 27 * stats.box_tests + 150 * stats.triangle_tests + 61 * stats.shadow_rays
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mesh-level", type=int, default=6, help="icosphere subdivisions: 6 = 81,920 triangles, 8 = 1,310,720")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    rt = importlib.import_module("ray-tracer_amd")
+    synth = importlib.import_module("ray-tracer_amd.synth")
+    lib = rt.Library()  # raises when librt_amd.so is missing: there is no fallback path
+    lib.init(local_rank)
+
+    mesh = synth.dragon_class_mesh(args.mesh_level)
+    scene = rt.SceneData([mesh], lights=synth.area_light())
+    sh = lib.scene_create(scene)
+    bvh = lib.bvh_build(sh)
+    lights, n_lights = scene.light_array()
+    cam = rt.make_camera(width=WIDTH, height=HEIGHT, **CAMERA)
+    feats = rt.features(shading=1, soft_shadow=1, multiple_rays=1)
+    params = rt.default_params(ray_multiplier=4)
+
+    # interleaved 16-row blocks, block b belongs to rank b % world
+    n_blocks = (HEIGHT + ROW_BLOCK - 1) // ROW_BLOCK
+    per_rank = (n_blocks + world - 1) // world
+    my_blocks = [b for b in range(rank, n_blocks, world)]
+    local = torch.zeros((per_rank * ROW_BLOCK, WIDTH, 3), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def render_frame(p, want_stats):
+        """Renders this rank's rows into `local` (block k of this rank at rows [k*16, k*16+16) of `local`)."""
+        total = rt.Stats()
+        if world == 1:
+            _, st = lib.render(bvh, cam, lights, n_lights, feats, p, WIDTH, HEIGHT, 0, HEIGHT, out=local.data_ptr(), device_ptr=1, stream=stream)
+            return st
+        for k, b in enumerate(my_blocks):
+            # block b covers Screen rows [b*16, ...): bottom-up rows [H - end, H - begin)
+            top, bot = b * ROW_BLOCK, min(HEIGHT, (b + 1) * ROW_BLOCK)
+            _, st = lib.render(bvh, cam, lights, n_lights, feats, p, WIDTH, HEIGHT, HEIGHT - bot, HEIGHT - top,
+                               out=local.data_ptr() + k * ROW_BLOCK * WIDTH * 12, device_ptr=1, stream=stream)
+            for name, _ in rt.Stats._fields_:
+                setattr(total, name, getattr(total, name) + getattr(st, name))
+        return total
+
+    def step():
+        st = render_frame(params, True)
+        if world > 1:
+            dist.gather(local, gathered, dst=0)
+        return st
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms, rays = 0.0, 0
+    for _ in range(args.steps):
+        st = step()
+        kernel_ms += st.kernel_ms
+        rays += st.total_rays()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(rays)], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, rays = float(tmax[0]), int(tsum[1])
+
+    # one untimed frame with test counting on, for the roofline numerator (counts are deterministic)
+    count_params = rt.default_params(ray_multiplier=4, count_tests=1)
+    cst = render_frame(count_params, True)
+    torch.cuda.synchronize()
+    my_pixels = WIDTH * sum(min(HEIGHT, (b + 1) * ROW_BLOCK) - b * ROW_BLOCK for b in my_blocks)
+    launch_bytes = algorithmic_bytes(cst, my_pixels)
+    launch_flops = algorithmic_flops(cst)
+    avg_kernel_s = kernel_ms / args.steps / 1e3
+
+    if rank == 0:
+        frame_ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "Mrays/s, dragon-class mesh 1080p 16spp soft shadows (16 light samples)",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": frame_ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[2]: dragon-class mesh ({scene.n_triangles} triangles, synthetic stand-in for the absent dragon.obj), "
+                            f"{WIDTH}x{HEIGHT}, BVH on, Phong + parallelogram light soft shadows (16 samples), 16 spp",
+                "triangles": scene.n_triangles,
+                "bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)),
+                "rays_per_frame": rays // args.steps,
+                "partition": "whole frame" if world == 1 else f"interleaved {ROW_BLOCK}-row blocks over {world} ranks, gather to rank 0",
+            },
+            "frame_ms": frame_ms,
+            "roofline": {
+                "kernel": "k_render",
+                "bound": "hbm",
+                "achieved": launch_bytes / avg_kernel_s / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": launch_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_launch": launch_bytes,
+                "valu": {"achieved": launch_flops / avg_kernel_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": launch_flops / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS},
+                "box_tests_per_ray": cst.box_tests / max(1, cst.total_rays()),
+                "triangle_tests_per_ray": cst.triangle_tests / max(1, cst.total_rays()),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(rt, scene, cam, feats, params)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(rt, scene, cam, feats, params):
+    """The oracle (oracle/cpu_ref.cpp, the CPU restatement of the reference's algorithm) timed on this
+    machine's host cores on every 24th row of the same frame at full sample count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as o
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    osc = o.OracleScene(scene)
+    row_step = 24
+    t0 = time.perf_counter()
+    _, st = osc.render(cam, feats, params, WIDTH, HEIGHT, row_step=row_step, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": st.total_rays() / dt / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"every {row_step}th row of the same 1920x1080 frame at 16 spp ({st.total_rays()} rays, {dt:.1f} s, OpenMP schedule(guided) over rows)",
+        "frame_ms_extrapolated": dt * row_step * 1e3,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -161,7 +161,8 @@ typedef struct rt_stats {
     uint64_t primary_rays, shadow_rays, bounce_rays, probe_rays;
     uint64_t box_tests, triangle_tests;
     uint64_t transparency_overflows;
-    float kernel_ms; /* device time of the render kernels of this call (HIP events) */
+    float kernel_ms;  /* device time of this call's traversal/shading kernel launches (HIP events on the call's stream) */
+    float resolve_ms; /* device time of the sample-resolve pass (0 when one sample per pixel) */
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device copy of geometry, materials, textures, skybox */

@@ -186,6 +186,7 @@ class Stats(C.Structure):
         ("triangle_tests", C.c_uint64),
         ("transparency_overflows", C.c_uint64),
         ("kernel_ms", C.c_float),
+        ("resolve_ms", C.c_float),
     ]
 
     def total_rays(self):

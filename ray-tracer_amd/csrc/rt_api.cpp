@@ -89,7 +89,7 @@ struct rt_bvh {
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
     DevBuf stats, frame, samples, dofFlags, rays, hits, misc, bloomWeights;
-    hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr;
 };
 
 namespace {
@@ -229,6 +229,7 @@ rt_status upload_bvh(rt_bvh* b)
     RT_HIP(upload(b->primOrder, flat.primOrder));
     RT_HIP(b->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
     RT_HIP(hipEventCreate(&b->evStart));
+    RT_HIP(hipEventCreate(&b->evMid));
     RT_HIP(hipEventCreate(&b->evStop));
     SceneView& v = b->view;
     v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
@@ -344,6 +345,7 @@ void rt_bvh_destroy(rt_bvh* b)
     for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
+    if (b->evMid) (void)hipEventDestroy(b->evMid);
     if (b->evStop) (void)hipEventDestroy(b->evStop);
     delete b;
 }
@@ -488,7 +490,7 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     // a synchronous wait is only needed when the caller wants numbers or host pixels back
     const bool wait = stats != nullptr || !devicePtr;
     if (stats) RT_HIP(hipEventRecord(b->evStart, s));
-    RT_HIP(launch_render(P, s));
+    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr));
     if (stats) RT_HIP(hipEventRecord(b->evStop, s));
     if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
     if (wait) RT_HIP(hipStreamSynchronize(s));
@@ -502,7 +504,8 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         stats->box_tests = h[STAT_BOX];
         stats->triangle_tests = h[STAT_TRI];
         stats->transparency_overflows = h[STAT_OVERFLOW];
-        RT_HIP(hipEventElapsedTime(&stats->kernel_ms, b->evStart, b->evStop));
+        RT_HIP(hipEventElapsedTime(&stats->kernel_ms, b->evStart, b->evMid));
+        RT_HIP(hipEventElapsedTime(&stats->resolve_ms, b->evMid, b->evStop));
     }
     return RT_OK;
 }

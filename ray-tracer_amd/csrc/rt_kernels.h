@@ -8,8 +8,9 @@ namespace rt {
 
 enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_COUNT };
 
-// Renders rows [P.rowBegin, P.rowEnd) into P.out.  Returns the HIP status of the launch.
-hipError_t launch_render(const FrameParams& P, hipStream_t stream);
+// Renders rows [P.rowBegin, P.rowEnd): the traversal/shading passes, then (more than one sample per pixel)
+// the resolve pass.  `afterPasses`, when not null, is recorded between the two.
+hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses);
 
 // n closest-hit queries; rays/hits are device pointers.
 hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n, rt_hit* hits, hipStream_t stream);

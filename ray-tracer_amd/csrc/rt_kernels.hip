@@ -194,7 +194,7 @@ hipError_t launch_render_t(const FrameParams& P, dim3 grid, size_t lds, hipStrea
 
 } // namespace
 
-hipError_t launch_render(const FrameParams& Pin, hipStream_t stream)
+hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses)
 {
     FrameParams P = Pin;
     const int rows = P.rowEnd - P.rowBegin;
@@ -218,6 +218,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream)
     } else {
         if ((e = pass(0, P.samplesPerPixel)) != hipSuccess) return e;
     }
+    if (afterPasses && (e = hipEventRecord(afterPasses, stream)) != hipSuccess) return e;
     if (P.samplesPerPixel > 1) {
         const size_t nPix = size_t(rows) * size_t(P.width);
         hipLaunchKernelGGL(k_resolve, dim3(uint32_t((nPix + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream, P);
