@@ -88,7 +88,7 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, samples, dofFlags, rays, hits, misc, bloomWeights;
+    DevBuf stats, frame, queue, queueCounters, samples, dofFlags, rays, hits, misc, bloomWeights;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr;
 };
 
@@ -342,7 +342,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -477,6 +477,17 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         P.dofFlags = static_cast<uint8_t*>(b->dofFlags.ptr);
     } else {
         P.f.depth_of_field = 0; // the reference ignores it when supersampling is on (render.cpp:96-98)
+    }
+    {
+        // hit queue of the two-kernel path: one 16-byte entry per (pixel, sample) of a pass, passes sized to
+        // at most 64 Mi entries (1 GiB)
+        const size_t want = nPix * size_t(spp);
+        const size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
+        RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
+        RT_HIP(b->queueCounters.reserve(64));
+        P.queue = static_cast<HitEntry*>(b->queue.ptr);
+        P.queueCounters = static_cast<unsigned int*>(b->queueCounters.ptr);
+        P.queueCapacity = cap;
     }
     float* dOut = outRgb;
     if (!devicePtr) {

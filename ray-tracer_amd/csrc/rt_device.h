@@ -13,6 +13,8 @@ namespace rt {
 // Per-light constants the reference recomputes at every hit (reference src/light.cpp:151-155,188-194);
 // they only depend on the light and the sampling tunables, so the host evaluates them once per frame with
 // the same fp32 operations.
+struct HitEntry;
+
 struct LightDev {
     int32_t type;
     float v[21];
@@ -44,6 +46,10 @@ struct FrameParams {
     int32_t sampleBegin, sampleEnd, samplesPerPixel;
     unsigned long long* stats; // primary, shadow, bounce, probe, box, tri, overflow
     int32_t countTests;
+    // two-kernel path: queue of primary hits, [0] = entries written, [1] = entries handed out
+    struct HitEntry* queue;
+    unsigned int* queueCounters;
+    size_t queueCapacity; // entries
 };
 
 struct Counts {
@@ -141,47 +147,58 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
     float tRoot;
     if (COUNT) cnt.box++;
     if (!box_entry(r, S.rootLo, S.rootHi, tRoot) || !(tRoot < tmax)) return -1;
+    constexpr int32_t DONE = INT32_MIN;
     int hit = -1;
     int sp = 0;
     int32_t cur = S.rootRef;
     float curT = tRoot;
+    // "while-while": all lanes of the wave walk inner nodes until each holds a leaf (or has run out), then
+    // all of them run their primitive tests together.  The per-lane visiting order is unchanged.
     while (true) {
-        bool skip = false;
-        if (PRUNE) {
-            const float best = hit >= 0 ? tmax : FLT_MAX;
-            skip = curT > best;
-        }
-        if (!skip) {
-            if (cur >= 0) {
+        while (cur >= 0) {
+            bool descend = true;
+            if (PRUNE) descend = !(curT > (hit >= 0 ? tmax : FLT_MAX));
+            if (descend) {
                 const NodeRec& nd = S.nodes[cur];
                 float tL, tR;
                 if (COUNT) cnt.box += 2;
-                bool vL = box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
-                bool vR = box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
+                const bool vL = box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
+                const bool vR = box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
                 const int32_t refL = nd.refL, refR = nd.refR;
                 if (vL && vR) {
-                    if (tL < tR) { st.push(sp++, refR, tR); cur = refL; curT = tL; }
-                    else { st.push(sp++, refL, tL); cur = refR; curT = tR; }
+                    const bool leftFirst = tL < tR;
+                    st.push(sp++, leftFirst ? refR : refL, leftFirst ? tR : tL);
+                    cur = leftFirst ? refL : refR;
+                    curT = leftFirst ? tL : tR;
                     continue;
                 }
-                if (vR) { cur = refR; curT = tR; continue; }
-                if (vL) { cur = refL; curT = tL; continue; }
-            } else {
-                int32_t slot = ~cur;
-                int32_t more;
-                do {
-                    const PrimRec& p = S.prims[slot];
-                    more = p.more;
-                    if (COUNT) cnt.tri++;
-                    float t;
-                    if (triangle_hit(r, p, tmax, t)) {
-                        tmax = t;
-                        hit = slot;
-                        if (ANY) return hit;
-                    }
-                    slot++;
-                } while (more > 0);
+                if (vL || vR) {
+                    cur = vR ? refR : refL;
+                    curT = vR ? tR : tL;
+                    continue;
+                }
             }
+            if (sp == 0) cur = DONE;
+            else st.pop(--sp, cur, curT);
+        }
+        if (cur == DONE) break;
+        bool test = true;
+        if (PRUNE) test = !(curT > (hit >= 0 ? tmax : FLT_MAX));
+        if (test) {
+            int32_t slot = ~cur;
+            int32_t more;
+            do {
+                const PrimRec& p = S.prims[slot];
+                more = p.more;
+                if (COUNT) cnt.tri++;
+                float t;
+                if (triangle_hit(r, p, tmax, t)) {
+                    tmax = t;
+                    hit = slot;
+                    if (ANY) return hit;
+                }
+                slot++;
+            } while (more > 0);
         }
         if (sp == 0) break;
         st.pop(--sp, cur, curT);
@@ -233,11 +250,21 @@ __device__ __forceinline__ vec3 texel_u8(const uint8_t* texels, const ImageRec& 
     return make3(float(px[0]) / 255.0f, float(px[1]) / 255.0f, float(px[2]) / 255.0f);
 }
 
-// reference src/texture.cpp:5-17 (nearest texel, wrap by fmod; the intermediates are double there)
+// std::round(double(x) - 0.5) for a float x, evaluated without doubles: x - 0.5 is exact in double, and
+// rounding halves away from zero gives floor(x) from 0.5 upwards, 0 inside (0, 0.5), and ceil(x - 1) at and
+// below zero (where the float subtraction can only round when the result is unaffected).
+__device__ __forceinline__ float round_minus_half(float x)
+{
+    return x >= 0.5f ? floorf(x) : (x > 0.0f ? 0.0f : ceilf(x - 1.0f));
+}
+
+// reference src/texture.cpp:5-17: nearest texel, wrapped with fmod.  The reference's intermediates are
+// double; every one of them is an integer-valued or exactly representable quantity, so the float
+// evaluation below produces the same index.
 __device__ __forceinline__ vec3 acquire_texel(const uint8_t* texels, const ImageRec& im, float u, float v)
 {
-    const float i = float(fmod(round(double(u * float(im.width)) - 0.5), double(im.width)));
-    const float j = float(fmod(round(double((1 - v) * float(im.height)) - 0.5), double(im.height)));
+    const float i = fmodf(round_minus_half(u * float(im.width)), float(im.width));
+    const float j = fmodf(round_minus_half((1 - v) * float(im.height)), float(im.height));
     return texel_u8(texels, im, int(j * float(im.width) + i));
 }
 
@@ -307,8 +334,9 @@ __device__ __forceinline__ vec3 skybox_color(const SceneView& S, vec3 dir)
         vt = -v.y;
         face = int(v.z < 0) + 4;
     }
-    const float tu = float(double(-(ut / maxA)) + 0.5);
-    const float tv = float(double(-(vt / maxA)) + 0.5);
+    // the reference adds the double literal 0.5 and narrows; for these magnitudes the float sum is identical
+    const float tu = -(ut / maxA) + 0.5f;
+    const float tv = -(vt / maxA) + 0.5f;
     const ImageRec& im = S.skybox[face];
     const int i = int(tu * float(im.width));
     float fj = (1.0f - tv) * float(im.height);
@@ -332,7 +360,9 @@ struct Rng {
     }
 };
 
-// Phong term, reference src/shading.cpp:6-39 (the exponent goes through double pow there)
+// Phong term, reference src/shading.cpp:6-39.  The reference's exponentiation resolves to C's double pow and is
+// narrowed to float; powf here differs from that by at most a few units in the last place of a factor that is
+// at most 1, i.e. below 1e-6 in the pixel value, and no ray decision depends on it.
 __device__ __forceinline__ vec3 phong(vec3 lightPos, vec3 lightColor, const RayD& r, float t, const Surface& s)
 {
     const vec3 P = r.o + (r.d * t);
@@ -347,7 +377,7 @@ __device__ __forceinline__ vec3 phong(vec3 lightPos, vec3 lightColor, const RayD
         const vec3 V = normalize(-r.o + P);
         const float rv = dot(R, V);
         const float specAngle = rv > 0 ? rv : 0;
-        specular = float(pow(double(specAngle), double(s.shininess)));
+        specular = powf(specAngle, s.shininess);
     }
     return lightColor * s.ks * specular + diffuse;
 }
@@ -632,6 +662,49 @@ __device__ vec3 render_sample(const FrameParams& P, int x, int y, int sidx, Stac
     const vec3 color = final_color<PRUNE, GLOSSY, COUNT>(P, o, d, rng, st, cnt, firstT);
     dofFlag = firstT != FLT_MAX && fabsf(P.p.dof_f - dlen * firstT) > P.p.dof;
     return color;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Two-kernel form of the same per-sample evaluation, used when a sample is one camera ray plus direct
+// lighting (no mirror / glossy / transparency / reflection-map / depth-of-field branch can trigger):
+//   primary pass: camera ray -> closest hit; misses are finished on the spot, hits are queued;
+//   direct pass : one lane per queued hit -> surface attributes, light samples, shadow rays, Phong.
+// Queueing the hits compacts them, so the second pass runs with full waves and fewer live registers.
+// ---------------------------------------------------------------------------------------------------
+struct HitEntry {
+    uint32_t work; // sample * pixelsInSlice + pixel (pixel = Screen-order index inside the rendered row slice)
+    float t;
+    int32_t slot;
+    uint32_t pad;
+};
+
+__device__ __forceinline__ void sample_camera_ray(const FrameParams& P, int x, int y, int sidx, Rng& rng, vec3& o, vec3& d)
+{
+    rng.pixelKey = rng_pixel_key(P.p.seed, uint32_t(y * P.width + x));
+    rng.glossCall = 0;
+    rng.sample = uint32_t(sidx);
+    const float W = float(P.width), H = float(P.height);
+    if (P.f.multiple_rays) {
+        const int n = P.p.ray_multiplier;
+        const int i = sidx / n, j = sidx - i * n;
+        rng.randCounter = 0;
+        const float randomx = float(rng.rand31() % 100) / 100.0f;
+        const float randomy = float(rng.rand31() % 100) / 100.0f;
+        const float px = (float(x) + (float(i) / float(n) + randomx)) / W * 2.0f - 1.0f;
+        const float py = (float(y) + (float(j) / float(n) + randomy)) / H * 2.0f - 1.0f;
+        camera_ray(P, px, py, o, d);
+    } else {
+        const float px = float(x) / W * 2.0f - 1.0f;
+        const float py = float(y) / H * 2.0f - 1.0f;
+        camera_ray(P, px, py, o, d);
+        rng.randCounter = 2;
+    }
+}
+
+__device__ __forceinline__ float* sample_slot(const FrameParams& P, size_t pix, int sidx)
+{
+    if (P.samplesPerPixel == 1) return P.out + pix * 3;
+    return P.samples + (size_t(sidx) * size_t(P.rowEnd - P.rowBegin) * size_t(P.width) + pix) * 3;
 }
 
 } // namespace rt

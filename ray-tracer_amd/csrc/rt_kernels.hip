@@ -6,8 +6,9 @@ namespace rt {
 
 namespace {
 
-constexpr int BLOCK = 256;  // 4 waves; each wave renders an 8x8 pixel tile, the block a 16x16 tile
-constexpr int TILE = 16;
+constexpr int BLOCK = 256;  // threads per block of the batch / bloom / resolve kernels
+constexpr int WAVE = 64;    // the render kernels run one wave per block: an 8x8 pixel tile at one sample index
+constexpr int TILE = 8;
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -36,38 +37,132 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t n)
     return base + idx;
 }
 
-// One lane = one (pixel, sample).  A wave covers an 8x8 pixel tile at one sample index, a block a 16x16
-// tile; consecutive logical blocks are the samples of one tile, then the next tile.
-template <bool PRUNE, bool GLOSSY, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) k_render(const FrameParams P)
+// One lane = one (pixel, sample).  A block is one wave covering an 8x8 pixel tile at one sample index;
+// consecutive logical blocks are the samples of one tile, then the next tile.
+struct LaneId {
+    int x, y, sidx;
+    size_t pix;
+    bool valid;
+};
+__device__ __forceinline__ LaneId lane_id(const FrameParams& P)
 {
-    extern __shared__ uint2 lds_stack[];
-    const int tid = int(threadIdx.x);
-    const int wave = tid >> 6, lane = tid & 63;
+    const int lane = int(threadIdx.x);
     const int tilesX = (P.width + TILE - 1) / TILE;
     const int nS = P.sampleEnd - P.sampleBegin;
     const uint32_t logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int tile = int(logical) / nS;
-    const int sidx = P.sampleBegin + int(logical) % nS;
-    const int bx = tile % tilesX, by = tile / tilesX;
-    const int x = bx * TILE + (wave & 1) * 8 + (lane & 7);
-    const int y = P.rowBegin + by * TILE + (wave >> 1) * 8 + (lane >> 3);
-    Stack st { lds_stack + tid, uint32_t(BLOCK) };
+    const int tile = int(logical / uint32_t(nS));
+    LaneId id;
+    id.sidx = P.sampleBegin + int(logical % uint32_t(nS));
+    id.x = (tile % tilesX) * TILE + (lane & 7);
+    id.y = P.rowBegin + (tile / tilesX) * TILE + (lane >> 3);
+    id.valid = id.x < P.width && id.y < P.rowEnd;
+    id.pix = size_t(P.rowEnd - 1 - id.y) * size_t(P.width) + size_t(id.x);
+    return id;
+}
+
+// General path: the whole evaluation of a sample (any feature combination) in one lane.
+template <bool PRUNE, bool GLOSSY, bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_render(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    const LaneId id = lane_id(P);
+    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
-    if (x < P.width && y < P.rowEnd) {
-        const size_t pix = size_t(P.rowEnd - 1 - y) * size_t(P.width) + size_t(x);
+    if (id.valid) {
         bool live = true;
-        if (P.f.depth_of_field && sidx > 0) live = P.dofFlags[pix] != 0;
+        if (P.f.depth_of_field && id.sidx > 0) live = P.dofFlags[id.pix] != 0;
         if (live) {
             bool dofFlag = false;
-            const vec3 c = render_sample<PRUNE, GLOSSY, COUNT>(P, x, y, sidx, st, cnt, dofFlag);
-            float* o;
-            if (P.samplesPerPixel == 1) o = P.out + pix * 3;
-            else o = P.samples + (size_t(sidx) * size_t(P.rowEnd - P.rowBegin) * size_t(P.width) + pix) * 3;
+            const vec3 c = render_sample<PRUNE, GLOSSY, COUNT>(P, id.x, id.y, id.sidx, st, cnt, dofFlag);
+            float* o = sample_slot(P, id.pix, id.sidx);
             o[0] = c.x;
             o[1] = c.y;
             o[2] = c.z;
-            if (P.f.depth_of_field && sidx == 0) P.dofFlags[pix] = dofFlag ? 1 : 0;
+            if (P.f.depth_of_field && id.sidx == 0) P.dofFlags[id.pix] = dofFlag ? 1 : 0;
+        }
+    }
+    flush_counts(cnt, P.stats);
+}
+
+// Two-kernel path, first kernel: camera ray and closest hit.  A miss is final (sky or black); a hit goes to
+// the queue, appended with one atomic per wave so that the hits of a tile stay together.
+template <bool PRUNE, bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    const LaneId id = lane_id(P);
+    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    Counts cnt;
+    int slot = -1;
+    float t = FLT_MAX;
+    if (id.valid) {
+        Rng rng;
+        vec3 o, d;
+        sample_camera_ray(P, id.x, id.y, id.sidx, rng, o, d);
+        const RayD r = make_ray(o, d);
+        cnt.primary++;
+        slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
+        if (slot < 0) {
+            const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, d) : splat3(0.0f);
+            float* out = sample_slot(P, id.pix, id.sidx);
+            out[0] = c.x;
+            out[1] = c.y;
+            out[2] = c.z;
+        }
+    }
+    const unsigned long long hits = __ballot(slot >= 0);
+    if (hits) {
+        const int lane = int(threadIdx.x);
+        unsigned int base = 0;
+        if (lane == __ffsll((long long)hits) - 1) base = atomicAdd(&P.queueCounters[0], (unsigned int)__popcll(hits));
+        base = __shfl(base, __ffsll((long long)hits) - 1, 64);
+        if (slot >= 0) {
+            const unsigned int at = base + (unsigned int)__popcll(hits & ((1ull << lane) - 1ull));
+            HitEntry e;
+            e.work = uint32_t(id.sidx - P.sampleBegin) * uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width)) + uint32_t(id.pix);
+            e.t = t;
+            e.slot = slot;
+            e.pad = 0;
+            P.queue[at] = e;
+        }
+    }
+    flush_counts(cnt, P.stats);
+}
+
+// Two-kernel path, second kernel: persistent waves take 64 queued hits at a time and evaluate the direct
+// lighting of each (reference src/light.cpp:124-220 for a hit that returns Lo, src/render.cpp:64-67).
+// Every wave leaves the loop once the hand-out cursor passes the entry count.
+template <bool PRUNE, bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_direct(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    const int lane = int(threadIdx.x);
+    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    Counts cnt;
+    const unsigned int total = P.queueCounters[0];
+    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    while (true) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(&P.queueCounters[1], 64u);
+        base = __shfl(base, 0, 64);
+        if (base >= total) break;
+        const unsigned int q = base + (unsigned int)lane;
+        if (q < total) {
+            const HitEntry e = P.queue[q];
+            const int sidx = P.sampleBegin + int(e.work / nPix);
+            const size_t pix = size_t(e.work % nPix);
+            const int x = int(pix % size_t(P.width));
+            const int y = P.rowEnd - 1 - int(pix / size_t(P.width));
+            Rng rng;
+            vec3 o, d;
+            sample_camera_ray(P, x, y, sidx, rng, o, d);
+            const RayD r = make_ray(o, d);
+            const Surface s = surface_at(P, r, e.t, e.slot);
+            const vec3 c = light_contribution<PRUNE, COUNT>(P, r, e.t, s, rng, st, cnt);
+            float* out = sample_slot(P, pix, sidx);
+            out[0] = c.x;
+            out[1] = c.y;
+            out[2] = c.z;
         }
     }
     flush_counts(cnt, P.stats);
@@ -178,21 +273,39 @@ __global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, 
     dst[idx * 3 + 2] = o.z;
 }
 
-size_t stack_bytes(const FrameParams& P)
+size_t stack_bytes(const FrameParams& P, int threads)
 {
     int depth = P.scene.stackDepth < 1 ? 1 : P.scene.stackDepth;
-    return size_t(BLOCK) * size_t(depth) * sizeof(uint2);
+    return size_t(threads) * size_t(depth) * sizeof(uint2);
 }
 
 template <bool PRUNE, bool GLOSSY>
 hipError_t launch_render_t(const FrameParams& P, dim3 grid, size_t lds, hipStream_t stream)
 {
-    if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true>), grid, dim3(BLOCK), lds, stream, P);
-    else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false>), grid, dim3(BLOCK), lds, stream, P);
+    if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true>), grid, dim3(WAVE), lds, stream, P);
+    else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false>), grid, dim3(WAVE), lds, stream, P);
+    return hipGetLastError();
+}
+
+template <bool PRUNE>
+hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size_t lds, hipStream_t stream)
+{
+    if (P.countTests) {
+        hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
+        hipLaunchKernelGGL((k_direct<PRUNE, true>), gridDirect, dim3(WAVE), lds, stream, P);
+    } else {
+        hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
+        hipLaunchKernelGGL((k_direct<PRUNE, false>), gridDirect, dim3(WAVE), lds, stream, P);
+    }
     return hipGetLastError();
 }
 
 } // namespace
+
+bool direct_only(const FrameParams& P)
+{
+    return !(P.f.recursive || P.f.glossy || P.f.transparency || P.f.depth_of_field || (P.f.environment_mapping && P.p.enabled_refl_map));
+}
 
 hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses)
 {
@@ -200,21 +313,35 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     const int rows = P.rowEnd - P.rowBegin;
     if (rows <= 0 || P.width <= 0) return hipSuccess;
     const uint32_t tiles = uint32_t((P.width + TILE - 1) / TILE) * uint32_t((rows + TILE - 1) / TILE);
-    const size_t lds = stack_bytes(P);
+    const size_t lds = stack_bytes(P, WAVE);
     const bool prune = !P.f.recursive && !P.f.transparency;
     const bool glossy = P.f.glossy != 0;
+    const bool split = P.queue != nullptr && direct_only(P);
+    hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         P.sampleBegin = sBegin;
         P.sampleEnd = sEnd;
         const dim3 grid(tiles * uint32_t(sEnd - sBegin));
+        if (split) {
+            if ((e = hipMemsetAsync(P.queueCounters, 0, 2 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+            const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
+            const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
+            return prune ? launch_split_t<true>(P, grid, gridDirect, lds, stream) : launch_split_t<false>(P, grid, gridDirect, lds, stream);
+        }
         if (prune) return glossy ? launch_render_t<true, true>(P, grid, lds, stream) : launch_render_t<true, false>(P, grid, lds, stream);
         return glossy ? launch_render_t<false, true>(P, grid, lds, stream) : launch_render_t<false, false>(P, grid, lds, stream);
     };
-    hipError_t e;
     if (P.f.depth_of_field && !P.f.multiple_rays && P.samplesPerPixel > 1) {
         // the centre rays decide per pixel whether the lens rays are traced at all
         if ((e = pass(0, 1)) != hipSuccess) return e;
         if ((e = pass(1, P.samplesPerPixel)) != hipSuccess) return e;
+    } else if (split) {
+        // bound the hit queue: at most queueCapacity (pixel, sample) pairs per pass
+        const size_t nPix = size_t(rows) * size_t(P.width);
+        int chunk = int(P.queueCapacity / nPix);
+        if (chunk < 1) chunk = 1;
+        for (int sb = 0; sb < P.samplesPerPixel; sb += chunk)
+            if ((e = pass(sb, sb + chunk < P.samplesPerPixel ? sb + chunk : P.samplesPerPixel)) != hipSuccess) return e;
     } else {
         if ((e = pass(0, P.samplesPerPixel)) != hipSuccess) return e;
     }
@@ -231,7 +358,7 @@ hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n
 {
     if (n == 0) return hipSuccess;
     const dim3 grid(uint32_t((n + BLOCK - 1) / BLOCK));
-    const size_t lds = stack_bytes(P);
+    const size_t lds = stack_bytes(P, BLOCK);
     if (!P.f.recursive && !P.f.transparency) hipLaunchKernelGGL(k_intersect<true>, grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
     else hipLaunchKernelGGL(k_intersect<false>, grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
     return hipGetLastError();
@@ -242,7 +369,7 @@ hipError_t launch_visibility(const FrameParams& P, const rt_ray* rays, uint64_t 
     const uint64_t total = n * uint64_t(nSamples);
     if (total == 0) return hipSuccess;
     const dim3 grid(uint32_t((total + BLOCK - 1) / BLOCK));
-    const size_t lds = stack_bytes(P);
+    const size_t lds = stack_bytes(P, BLOCK);
     if (!P.f.recursive && !P.f.transparency) hipLaunchKernelGGL(k_visibility<true>, grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
     else hipLaunchKernelGGL(k_visibility<false>, grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
     return hipGetLastError();
