@@ -88,7 +88,7 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, samples, dofFlags, rays, hits, misc, bloomWeights;
+    DevBuf stats, frame, queue, queueCounters, visibility, samples, dofFlags, rays, hits, misc, bloomWeights;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr;
 };
 
@@ -131,8 +131,26 @@ void fill_lights(const rt_light* lights, int n, const rt_features& f, const rt_p
             d.nB = tj;
             d.draws = (f.soft_shadow || f.shading) ? 2 * ti * tj : 0;
         }
+        d.drawBase = drawsPerHit;
         drawsPerHit += d.draws;
     }
+}
+
+// Numbers the light samples that cast a shadow ray under the given features; returns their count per hit.
+int number_shadow_samples(LightDev* lights, int n, const rt_features& f)
+{
+    int at = 0;
+    for (int i = 0; i < n; i++) {
+        LightDev& d = lights[i];
+        const bool enabled = d.type == RT_LIGHT_POINT || f.soft_shadow || f.shading;
+        const bool shadowed = d.type == RT_LIGHT_POINT ? f.hard_shadow != 0 : f.soft_shadow != 0;
+        d.shadowBase = -1;
+        if (enabled && shadowed) {
+            d.shadowBase = at;
+            at += d.nA * d.nB;
+        }
+    }
+    return at;
 }
 
 // Trackball state, reference framework/src/trackball.cpp:23-31,71-74,117-126 and glm's Euler-angle quaternion
@@ -342,7 +360,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -463,6 +481,7 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     if (nLights > MAX_LIGHTS) return fail(RT_ERR_LIMIT, "at most " + std::to_string(int(MAX_LIGHTS)) + " lights per frame");
     fill_lights(lights, nLights, *features, *params, P.lights, P.drawsPerHit);
     P.nLights = nLights;
+    P.shadowSamplesPerHit = number_shadow_samples(P.lights, nLights, *features);
 
     int spp = 1;
     if (features->multiple_rays) spp = params->ray_multiplier * params->ray_multiplier;
@@ -485,8 +504,10 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         const size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
         RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
         RT_HIP(b->queueCounters.reserve(64));
+        RT_HIP(b->visibility.reserve(cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1)));
         P.queue = static_cast<HitEntry*>(b->queue.ptr);
-        P.queueCounters = static_cast<unsigned int*>(b->queueCounters.ptr);
+        P.queueCounters = static_cast<unsigned long long*>(b->queueCounters.ptr);
+        P.visibility = static_cast<uint8_t*>(b->visibility.ptr);
         P.queueCapacity = cap;
     }
     float* dOut = outRgb;

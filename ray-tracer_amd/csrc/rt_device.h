@@ -22,6 +22,8 @@ struct LightDev {
     int32_t nA, nB;     // trip counts of the reference's sample loops (its float loop bounds evaluated on the host)
     float step[3];      // segment: sampleDistanceSegment
     int32_t draws;      // rand() calls one evaluation of this light consumes
+    int32_t drawBase;   // rand() calls the lights before this one consume at a hit
+    int32_t shadowBase; // index of this light's first sample among the hit's shadow-casting samples, or -1
 };
 
 enum { MAX_LIGHTS = 16 };
@@ -48,8 +50,10 @@ struct FrameParams {
     int32_t countTests;
     // two-kernel path: queue of primary hits, [0] = entries written, [1] = entries handed out
     struct HitEntry* queue;
-    unsigned int* queueCounters;
-    size_t queueCapacity; // entries
+    unsigned long long* queueCounters; // [0] hits queued, [1] shadow work items handed out
+    size_t queueCapacity;        // entries
+    uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
+    int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features
 };
 
 struct Counts {
@@ -394,50 +398,67 @@ __device__ __forceinline__ float visibility(const FrameParams& P, vec3 samplePos
     return intersect<PRUNE, true, COUNT>(P, shadow, tmax, st, cnt) >= 0 ? 0.0f : 1.0f;
 }
 
-// reference src/light.cpp:124-220, with the two samplers (:22-64) inlined.  All light types run through one
-// sample loop so the kernel holds a single copy of the shadow-ray traversal and of the Phong term.
+// Sample k of light L (reference src/light.cpp:22-64 with the loop bookkeeping of :160-167,195-201): position
+// and colour.  `draw` is the index on the rand() stream of the first draw this sample consumes (a segment
+// sample takes one draw, a parallelogram sample two, a point light none).
+__device__ __forceinline__ void light_sample(const LightDev& L, int k, uint32_t pixelKey, uint32_t sample, uint32_t draw, vec3& position, vec3& color)
+{
+    if (L.type == RT_LIGHT_POINT) {
+        position = load3(L.v);
+        color = load3(L.v + 3);
+    } else if (L.type == RT_LIGHT_SEGMENT) {
+        const vec3 e0 = load3(L.v), e1 = load3(L.v + 3), c0 = load3(L.v + 6), c1 = load3(L.v + 9);
+        const float randomUniform = float(int(rng_u32(pixelKey, sample, RNG_STREAM_RAND, draw) >> 1) % 50) / 50.0f;
+        const vec3 randomAddition = load3(L.step) * randomUniform;
+        const float alpha = float(k) * L.recA;
+        position = (e0 * (1 - alpha) + e1 * alpha) + randomAddition;
+        float p0 = 0.5f, p1 = 0.5f;
+        if (L.recB != 0) {
+            p1 = length(position - e0) * L.recB;
+            p0 = 1 - p1;
+        }
+        color = p0 * c0 + p1 * c1;
+    } else {
+        const int i = k / L.nB, j = k - i * L.nB;
+        const vec3 v0 = load3(L.v), e01 = load3(L.v + 3), e02 = load3(L.v + 6);
+        const vec3 c0 = load3(L.v + 9), c1 = load3(L.v + 12), c2 = load3(L.v + 15), c3 = load3(L.v + 18);
+        const float ri = float(int(rng_u32(pixelKey, sample, RNG_STREAM_RAND, draw) >> 1) % 50) / 50.0f + float(i);
+        const float rj = float(int(rng_u32(pixelKey, sample, RNG_STREAM_RAND, draw + 1u) >> 1) % 50) / 50.0f + float(j);
+        const float x = ri * L.recA, y = rj * L.recB;
+        position = (v0 + e01 * x) + e02 * y;
+        color = (1 - y) * (x * c1 + (1 - x) * c0) + y * (x * c3 + (1 - x) * c2);
+    }
+}
+__device__ __forceinline__ uint32_t light_draws_per_sample(int type) { return type == RT_LIGHT_POINT ? 0u : (type == RT_LIGHT_SEGMENT ? 1u : 2u); }
+__device__ __forceinline__ bool light_enabled(const FrameParams& P, int type) { return type == RT_LIGHT_POINT || P.f.soft_shadow || P.f.shading; }
+__device__ __forceinline__ bool light_shadowed(const FrameParams& P, int type) { return type == RT_LIGHT_POINT ? P.f.hard_shadow != 0 : P.f.soft_shadow != 0; }
+// weight the reference applies to one sample's shade (light.cpp:141-143,175-178,209-212)
+__device__ __forceinline__ vec3 light_weight(const LightDev& L, vec3 shade)
+{
+    if (L.type == RT_LIGHT_SEGMENT) return shade * L.recA;
+    if (L.type == RT_LIGHT_PARALLELOGRAM) return shade * L.recA * L.recB;
+    return shade;
+}
+
+// reference src/light.cpp:124-220.  All light types run through one sample loop so the kernel holds a single
+// copy of the shadow-ray traversal and of the Phong term.
 template <bool PRUNE, bool COUNT>
 __device__ vec3 light_contribution(const FrameParams& P, const RayD& r, float t, const Surface& s, Rng& rng, Stack st, Counts& cnt)
 {
     vec3 shading = splat3(0.0f);
     for (int li = 0; li < P.nLights; li++) {
         const LightDev& L = P.lights[li];
-        const int type = L.type;
-        if (type != RT_LIGHT_POINT && !(P.f.soft_shadow || P.f.shading)) continue;
-        const bool shadowed = type == RT_LIGHT_POINT ? P.f.hard_shadow != 0 : P.f.soft_shadow != 0;
-        const int nB = L.nB, total = L.nA * nB;
+        if (!light_enabled(P, L.type)) continue;
+        const bool shadowed = light_shadowed(P, L.type);
+        const int total = L.nA * L.nB;
+        const uint32_t per = light_draws_per_sample(L.type);
         for (int k = 0; k < total; k++) {
             vec3 position, color;
-            if (type == RT_LIGHT_POINT) {
-                position = load3(L.v);
-                color = load3(L.v + 3);
-            } else if (type == RT_LIGHT_SEGMENT) {
-                const vec3 e0 = load3(L.v), e1 = load3(L.v + 3), c0 = load3(L.v + 6), c1 = load3(L.v + 9);
-                const float randomUniform = float(rng.rand31() % 50) / 50.0f;
-                const vec3 randomAddition = load3(L.step) * randomUniform;
-                const float alpha = float(k) * L.recA;
-                position = (e0 * (1 - alpha) + e1 * alpha) + randomAddition;
-                float p0 = 0.5f, p1 = 0.5f;
-                if (L.recB != 0) {
-                    p1 = length(position - e0) * L.recB;
-                    p0 = 1 - p1;
-                }
-                color = p0 * c0 + p1 * c1;
-            } else {
-                const int i = k / nB, j = k - i * nB;
-                const vec3 v0 = load3(L.v), e01 = load3(L.v + 3), e02 = load3(L.v + 6);
-                const vec3 c0 = load3(L.v + 9), c1 = load3(L.v + 12), c2 = load3(L.v + 15), c3 = load3(L.v + 18);
-                const float ri = float(rng.rand31() % 50) / 50.0f + float(i);
-                const float rj = float(rng.rand31() % 50) / 50.0f + float(j);
-                const float x = ri * L.recA, y = rj * L.recB;
-                position = (v0 + e01 * x) + e02 * y;
-                color = (1 - y) * (x * c1 + (1 - x) * c0) + y * (x * c3 + (1 - x) * c2);
-            }
+            light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter, position, color);
+            rng.randCounter += per;
             const float lighted = shadowed ? visibility<PRUNE, COUNT>(P, position, r, t, st, cnt) : 1.0f;
-            vec3 shade = P.f.shading ? phong(position, color, r, t, s) : s.kd;
-            if (type == RT_LIGHT_SEGMENT) shade = shade * L.recA;
-            else if (type == RT_LIGHT_PARALLELOGRAM) shade = shade * L.recA * L.recB;
-            shading = shading + shade * lighted;
+            const vec3 shade = P.f.shading ? phong(position, color, r, t, s) : s.kd;
+            shading = shading + light_weight(L, shade) * lighted;
         }
     }
     return shading;

@@ -113,9 +113,10 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
     const unsigned long long hits = __ballot(slot >= 0);
     if (hits) {
         const int lane = int(threadIdx.x);
+        const int leader = __ffsll((long long)hits) - 1;
         unsigned int base = 0;
-        if (lane == __ffsll((long long)hits) - 1) base = atomicAdd(&P.queueCounters[0], (unsigned int)__popcll(hits));
-        base = __shfl(base, __ffsll((long long)hits) - 1, 64);
+        if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[0], (unsigned long long)__popcll(hits));
+        base = __shfl(base, leader, 64);
         if (slot >= 0) {
             const unsigned int at = base + (unsigned int)__popcll(hits & ((1ull << lane) - 1ull));
             HitEntry e;
@@ -129,43 +130,180 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
     flush_counts(cnt, P.stats);
 }
 
-// Two-kernel path, second kernel: persistent waves take 64 queued hits at a time and evaluate the direct
-// lighting of each (reference src/light.cpp:124-220 for a hit that returns Lo, src/render.cpp:64-67).
-// Every wave leaves the loop once the hand-out cursor passes the entry count.
+// Recomputes the camera ray of a queued hit from its work id.
+__device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e, uint32_t nPix, Rng& rng, RayD& r, size_t& pix, int& sidx)
+{
+    sidx = P.sampleBegin + int(e.work / nPix);
+    pix = size_t(e.work % nPix);
+    const int x = int(pix % size_t(P.width));
+    const int y = P.rowEnd - 1 - int(pix / size_t(P.width));
+    vec3 o, d;
+    sample_camera_ray(P, x, y, sidx, rng, o, d);
+    r = make_ray(o, d);
+}
+
+// Shadow pass: one any-hit query per (queued hit, shadow-casting light sample) — testVisibilityLightSample,
+// reference src/light.cpp:68-89.  Persistent waves; a lane whose ray has ended takes the next work item as
+// soon as enough lanes of its wave are idle, so lanes do not wait for the slowest ray of a fixed batch.
+// Work item w = hit * samplesPerHit + j keeps the rays of one hit (same origin) in neighbouring lanes.
+// Every wave leaves once the hand-out cursor has passed the item count and its own rays have ended.
 template <bool PRUNE, bool COUNT>
-__global__ void __launch_bounds__(WAVE) k_direct(const FrameParams P)
+__global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
 {
     extern __shared__ uint2 lds_stack[];
     const int lane = int(threadIdx.x);
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
-    const unsigned int total = P.queueCounters[0];
+    const SceneView& S = P.scene;
+    const unsigned long long perHit = (unsigned long long)P.shadowSamplesPerHit;
+    const unsigned long long total = P.queueCounters[0] * perHit;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    constexpr int32_t DONE = INT32_MIN;
+    constexpr int REFILL_BELOW = 40; // leave the traversal loop to refill once fewer lanes than this are busy
+    bool active = false, exhausted = false;
+    RayD r;
+    float tmax = 1.0f, curT = 0.0f;
+    int32_t cur = DONE;
+    int sp = 0;
+    unsigned long long work = 0;
     while (true) {
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(&P.queueCounters[1], 64u);
-        base = __shfl(base, 0, 64);
-        if (base >= total) break;
-        const unsigned int q = base + (unsigned int)lane;
-        if (q < total) {
-            const HitEntry e = P.queue[q];
-            const int sidx = P.sampleBegin + int(e.work / nPix);
-            const size_t pix = size_t(e.work % nPix);
-            const int x = int(pix % size_t(P.width));
-            const int y = P.rowEnd - 1 - int(pix / size_t(P.width));
-            Rng rng;
-            vec3 o, d;
-            sample_camera_ray(P, x, y, sidx, rng, o, d);
-            const RayD r = make_ray(o, d);
-            const Surface s = surface_at(P, r, e.t, e.slot);
-            const vec3 c = light_contribution<PRUNE, COUNT>(P, r, e.t, s, rng, st, cnt);
-            float* out = sample_slot(P, pix, sidx);
-            out[0] = c.x;
-            out[1] = c.y;
-            out[2] = c.z;
+        const unsigned long long idle = __ballot(!active);
+        if (idle && !exhausted) {
+            const int leader = __ffsll((long long)idle) - 1;
+            const unsigned long long want = (unsigned long long)__popcll(idle);
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&P.queueCounters[1], want);
+            base = __shfl(base, leader, 64);
+            exhausted = base + want >= total;
+            if (!active) {
+                work = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
+                if (work < total) {
+                    const HitEntry e = P.queue[work / perHit];
+                    const int j = int(work % perHit);
+                    Rng rng;
+                    RayD cam;
+                    size_t pix;
+                    int sidx;
+                    hit_ray(P, e, nPix, rng, cam, pix, sidx);
+                    // which light and which of its samples: the last light whose first shadow sample is <= j
+                    int li = 0;
+                    for (int i = 0; i < P.nLights; i++)
+                        if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
+                    const LightDev& L = P.lights[li];
+                    const int k = j - L.shadowBase;
+                    vec3 position, color;
+                    light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                    const float epsilon = 0.00001f;
+                    const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
+                    r = make_ray(origin, position - origin);
+                    cnt.shadow++;
+                    float tRoot;
+                    if (COUNT) cnt.box++;
+                    if (box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f) {
+                        active = true;
+                        tmax = 1.0f;
+                        cur = S.rootRef;
+                        curT = tRoot;
+                        sp = 0;
+                    } else {
+                        P.visibility[work] = 1;
+                    }
+                }
+            }
+        }
+        if (!__ballot(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        while (true) {
+            if (active) {
+                // inner nodes until this lane holds a leaf or has run out (same visiting order as traverse<>)
+                while (cur >= 0) {
+                    const NodeRec& nd = S.nodes[cur];
+                    float tL, tR;
+                    if (COUNT) cnt.box += 2;
+                    const bool vL = box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
+                    const bool vR = box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
+                    const int32_t refL = nd.refL, refR = nd.refR;
+                    if (vL && vR) {
+                        const bool leftFirst = tL < tR;
+                        st.push(sp++, leftFirst ? refR : refL, leftFirst ? tR : tL);
+                        cur = leftFirst ? refL : refR;
+                        curT = leftFirst ? tL : tR;
+                    } else if (vL || vR) {
+                        cur = vR ? refR : refL;
+                        curT = vR ? tR : tL;
+                    } else if (sp == 0) {
+                        cur = DONE;
+                    } else {
+                        st.pop(--sp, cur, curT);
+                    }
+                }
+                bool blocked = false;
+                if (cur != DONE) {
+                    int32_t slot = ~cur;
+                    int32_t more;
+                    do {
+                        const PrimRec& p = S.prims[slot];
+                        more = p.more;
+                        if (COUNT) cnt.tri++;
+                        float t;
+                        if (triangle_hit(r, p, tmax, t)) {
+                            blocked = true;
+                            break;
+                        }
+                        slot++;
+                    } while (more > 0);
+                }
+                if (blocked || cur == DONE || sp == 0) {
+                    P.visibility[work] = blocked ? 0 : 1;
+                    active = false;
+                } else {
+                    st.pop(--sp, cur, curT);
+                }
+            }
+            const int busy = __popcll(__ballot(active));
+            if (busy == 0 || (!exhausted && busy < REFILL_BELOW)) break;
         }
     }
     flush_counts(cnt, P.stats);
+}
+
+// Shade pass: one lane per queued hit — direct lighting with the visibility bits of the shadow pass
+// (reference src/light.cpp:124-220 for a hit whose colour is Lo, src/render.cpp:64-67).
+__global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
+{
+    const unsigned int nHits = (unsigned int)P.queueCounters[0];
+    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
+        const HitEntry e = P.queue[q];
+        Rng rng;
+        RayD r;
+        size_t pix;
+        int sidx;
+        hit_ray(P, e, nPix, rng, r, pix, sidx);
+        const Surface s = surface_at(P, r, e.t, e.slot);
+        const uint8_t* vis = P.visibility + size_t(q) * size_t(P.shadowSamplesPerHit);
+        vec3 shading = splat3(0.0f);
+        for (int li = 0; li < P.nLights; li++) {
+            const LightDev& L = P.lights[li];
+            if (!light_enabled(P, L.type)) continue;
+            const bool shadowed = light_shadowed(P, L.type);
+            const int total = L.nA * L.nB;
+            const uint32_t per = light_draws_per_sample(L.type);
+            for (int k = 0; k < total; k++) {
+                vec3 position, color;
+                light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
+                const float lighted = shadowed ? float(vis[L.shadowBase + k]) : 1.0f;
+                const vec3 shade = P.f.shading ? phong(position, color, r, e.t, s) : s.kd;
+                shading = shading + light_weight(L, shade) * lighted;
+            }
+        }
+        float* out = sample_slot(P, pix, sidx);
+        out[0] = shading.x;
+        out[1] = shading.y;
+        out[2] = shading.z;
+    }
 }
 
 // Sums the sample planes of each pixel in sample order and divides like the reference does:
@@ -287,16 +425,31 @@ hipError_t launch_render_t(const FrameParams& P, dim3 grid, size_t lds, hipStrea
     return hipGetLastError();
 }
 
+// Blocks of `kernel` that can be resident on the whole chip at once (persistent kernels are sized to this).
+template <class K>
+uint32_t resident_blocks(K kernel, int threads, size_t lds)
+{
+    int perCu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u * 8u;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, lds) != hipSuccess || perCu < 1) perCu = 4;
+    return uint32_t(perCu) * uint32_t(prop.multiProcessorCount);
+}
+
 template <bool PRUNE>
 hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size_t lds, hipStream_t stream)
 {
-    if (P.countTests) {
-        hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
-        hipLaunchKernelGGL((k_direct<PRUNE, true>), gridDirect, dim3(WAVE), lds, stream, P);
-    } else {
-        hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
-        hipLaunchKernelGGL((k_direct<PRUNE, false>), gridDirect, dim3(WAVE), lds, stream, P);
+    if (P.countTests) hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
+    else hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
+    if (P.shadowSamplesPerHit > 0) {
+        static const uint32_t residentCount = resident_blocks(k_shadow<PRUNE, true>, WAVE, lds);
+        static const uint32_t resident = resident_blocks(k_shadow<PRUNE, false>, WAVE, lds);
+        const uint32_t cap = P.countTests ? residentCount : resident;
+        const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
+        if (P.countTests) hipLaunchKernelGGL((k_shadow<PRUNE, true>), g, dim3(WAVE), lds, stream, P);
+        else hipLaunchKernelGGL((k_shadow<PRUNE, false>), g, dim3(WAVE), lds, stream, P);
     }
+    hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     return hipGetLastError();
 }
 
@@ -316,14 +469,14 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     const size_t lds = stack_bytes(P, WAVE);
     const bool prune = !P.f.recursive && !P.f.transparency;
     const bool glossy = P.f.glossy != 0;
-    const bool split = P.queue != nullptr && direct_only(P);
+    const bool split = P.queue != nullptr && P.f.accel_structure && direct_only(P);
     hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         P.sampleBegin = sBegin;
         P.sampleEnd = sEnd;
         const dim3 grid(tiles * uint32_t(sEnd - sBegin));
         if (split) {
-            if ((e = hipMemsetAsync(P.queueCounters, 0, 2 * sizeof(unsigned int), stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(P.queueCounters, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             return prune ? launch_split_t<true>(P, grid, gridDirect, lds, stream) : launch_split_t<false>(P, grid, gridDirect, lds, stream);
