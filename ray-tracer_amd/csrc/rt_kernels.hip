@@ -143,40 +143,53 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
 }
 
 // Shadow pass: one any-hit query per (queued hit, shadow-casting light sample) — testVisibilityLightSample,
-// reference src/light.cpp:68-89.  Persistent waves; a lane whose ray has ended takes the next work item as
-// soon as enough lanes of its wave are idle, so lanes do not wait for the slowest ray of a fixed batch.
-// Work item w = hit * samplesPerHit + j keeps the rays of one hit (same origin) in neighbouring lanes.
-// Every wave leaves once the hand-out cursor has passed the item count and its own rays have ended.
-template <bool PRUNE, bool COUNT>
+// reference src/light.cpp:68-89 — traced as PACKETS of 16 rays, one packet per 16-lane row of the wave.
+//
+// Work item w = hit * samplesPerHit + j; packet p holds items 16p .. 16p+15, i.e. the shadow rays of one hit
+// point towards one area light (or of neighbouring hits towards a point light): nearly identical rays.  The
+// 16 lanes of a row walk the hierarchy together with ONE shared stack and fetch the same node record, so a
+// node costs one cache-line access per packet instead of one per ray.
+//
+// This is exact, not an approximation: each stack entry carries the 16-bit set of rays that entered that
+// node through box tests of their own, a ray only tests the primitives of leaves it is in, and the answer of
+// an any-hit query ("is any primitive accepted before the light") does not depend on the order in which the
+// nodes a ray enters are visited.  So every ray performs exactly the box and primitive tests the reference's
+// traversal would make for it until its first accepted primitive, and gets the same boolean.
+//
+// Persistent waves: a row whose packet has ended takes the next one from a global cursor; every row stops
+// once the cursor has passed the packet count.
+template <bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
 {
-    extern __shared__ uint2 lds_stack[];
+    __shared__ uint2 packetStack[4][RT_MAX_LEVELS + 1];
     const int lane = int(threadIdx.x);
-    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    const int row = lane >> 4, col = lane & 15;
     Counts cnt;
     const SceneView& S = P.scene;
     const unsigned long long perHit = (unsigned long long)P.shadowSamplesPerHit;
     const unsigned long long total = P.queueCounters[0] * perHit;
+    const unsigned long long nPackets = (total + 15ull) / 16ull;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
-    constexpr int32_t DONE = INT32_MIN;
-    constexpr int REFILL_BELOW = 40; // leave the traversal loop to refill once fewer lanes than this are busy
-    bool active = false, exhausted = false;
+    auto row_mask = [&](bool pred) -> uint32_t { return uint32_t((__ballot(pred) >> (16 * row)) & 0xffffull); };
+    uint2* stack = packetStack[row];
+    bool idle = true, finished = false; // uniform within a row
     RayD r;
-    float tmax = 1.0f, curT = 0.0f;
-    int32_t cur = DONE;
-    int sp = 0;
+    bool traced = false, blocked = false; // this lane's ray passed the root gate / has been found occluded
     unsigned long long work = 0;
+    uint32_t alive = 0, mask = 0;         // uniform within a row: rays still undecided / rays inside `cur`
+    int32_t cur = 0;
+    int sp = 0;
     while (true) {
-        const unsigned long long idle = __ballot(!active);
-        if (idle && !exhausted) {
-            const int leader = __ffsll((long long)idle) - 1;
-            const unsigned long long want = (unsigned long long)__popcll(idle);
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&P.queueCounters[1], want);
-            base = __shfl(base, leader, 64);
-            exhausted = base + want >= total;
-            if (!active) {
-                work = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
+        if (idle && !finished) {
+            unsigned long long pk = 0;
+            if (col == 0) pk = atomicAdd(&P.queueCounters[1], 1ull);
+            pk = __shfl(pk, row * 16, 64);
+            if (pk >= nPackets) {
+                finished = true;
+            } else {
+                work = pk * 16ull + (unsigned long long)col;
+                traced = false;
+                blocked = false;
                 if (work < total) {
                     const HitEntry e = P.queue[work / perHit];
                     const int j = int(work % perHit);
@@ -199,71 +212,70 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
                     cnt.shadow++;
                     float tRoot;
                     if (COUNT) cnt.box++;
-                    if (box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f) {
-                        active = true;
-                        tmax = 1.0f;
-                        cur = S.rootRef;
-                        curT = tRoot;
-                        sp = 0;
-                    } else {
-                        P.visibility[work] = 1;
-                    }
+                    // root gate against the shadow ray's own bound t = 1 (…hierarchy.cpp:296-301)
+                    traced = box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f;
+                    if (!traced) P.visibility[work] = 1;
+                }
+                alive = row_mask(traced);
+                if (alive) {
+                    idle = false;
+                    cur = S.rootRef;
+                    mask = alive;
+                    sp = 0;
                 }
             }
         }
-        if (!__ballot(active)) {
-            if (exhausted) break;
+        if (!__ballot(!idle)) {
+            if (!__ballot(!finished)) break;
             continue;
         }
-        while (true) {
-            if (active) {
-                // inner nodes until this lane holds a leaf or has run out (same visiting order as traverse<>)
-                while (cur >= 0) {
+        if (!idle) {
+            const uint32_t in = mask & alive;
+            const bool mine = (in >> col) & 1u;
+            bool descend = false;
+            if (in) {
+                if (cur >= 0) {
                     const NodeRec& nd = S.nodes[cur];
                     float tL, tR;
-                    if (COUNT) cnt.box += 2;
-                    const bool vL = box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
-                    const bool vR = box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
+                    if (COUNT && mine) cnt.box += 2;
+                    const bool vL = mine && box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
+                    const bool vR = mine && box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
+                    const uint32_t mL = row_mask(vL), mR = row_mask(vR);
                     const int32_t refL = nd.refL, refR = nd.refR;
-                    if (vL && vR) {
-                        const bool leftFirst = tL < tR;
-                        st.push(sp++, leftFirst ? refR : refL, leftFirst ? tR : tL);
-                        cur = leftFirst ? refL : refR;
-                        curT = leftFirst ? tL : tR;
-                    } else if (vL || vR) {
-                        cur = vR ? refR : refL;
-                        curT = vR ? tR : tL;
-                    } else if (sp == 0) {
-                        cur = DONE;
-                    } else {
-                        st.pop(--sp, cur, curT);
+                    if (mL && mR) {
+                        if (col == 0) stack[sp] = make_uint2(uint32_t(refR), mR);
+                        sp++;
                     }
-                }
-                bool blocked = false;
-                if (cur != DONE) {
+                    if (mL | mR) {
+                        cur = mL ? refL : refR;
+                        mask = mL ? mL : mR;
+                        descend = true;
+                    }
+                } else {
                     int32_t slot = ~cur;
                     int32_t more;
                     do {
                         const PrimRec& p = S.prims[slot];
                         more = p.more;
-                        if (COUNT) cnt.tri++;
+                        const bool test = mine && !blocked;
+                        if (COUNT && test) cnt.tri++;
                         float t;
-                        if (triangle_hit(r, p, tmax, t)) {
-                            blocked = true;
-                            break;
-                        }
+                        if (test && triangle_hit(r, p, 1.0f, t)) blocked = true;
                         slot++;
                     } while (more > 0);
-                }
-                if (blocked || cur == DONE || sp == 0) {
-                    P.visibility[work] = blocked ? 0 : 1;
-                    active = false;
-                } else {
-                    st.pop(--sp, cur, curT);
+                    alive &= ~row_mask(blocked);
                 }
             }
-            const int busy = __popcll(__ballot(active));
-            if (busy == 0 || (!exhausted && busy < REFILL_BELOW)) break;
+            if (!descend) {
+                if (sp == 0 || alive == 0) {
+                    if (traced) P.visibility[work] = blocked ? 0 : 1;
+                    idle = true;
+                } else {
+                    const uint2 e = stack[--sp];
+                    cur = int32_t(e.x);
+                    mask = e.y;
+                }
+            }
         }
     }
     flush_counts(cnt, P.stats);
@@ -442,12 +454,12 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
     if (P.countTests) hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
     else hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
     if (P.shadowSamplesPerHit > 0) {
-        static const uint32_t residentCount = resident_blocks(k_shadow<PRUNE, true>, WAVE, lds);
-        static const uint32_t resident = resident_blocks(k_shadow<PRUNE, false>, WAVE, lds);
+        static const uint32_t residentCount = resident_blocks(k_shadow<true>, WAVE, 0);
+        static const uint32_t resident = resident_blocks(k_shadow<false>, WAVE, 0);
         const uint32_t cap = P.countTests ? residentCount : resident;
         const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
-        if (P.countTests) hipLaunchKernelGGL((k_shadow<PRUNE, true>), g, dim3(WAVE), lds, stream, P);
-        else hipLaunchKernelGGL((k_shadow<PRUNE, false>), g, dim3(WAVE), lds, stream, P);
+        if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), 0, stream, P);
+        else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), 0, stream, P);
     }
     hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     return hipGetLastError();
