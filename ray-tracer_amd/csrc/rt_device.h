@@ -62,10 +62,10 @@ struct Counts {
 
 struct RayD {
     vec3 o, d;
-    // per-axis reciprocal and the two direction classes the slab test branches on (reference
-    // src/intersect.cpp:114-126); a function of the ray only, so computed once per ray
+    // per-axis reciprocal and "direction component is zero" class of the slab test (reference
+    // src/intersect.cpp:114-126); functions of the ray only, so computed once per ray
     vec3 inv;
-    bool zx, zy, zz, px, py, pz;
+    bool zx, zy, zz;
 };
 
 __device__ __forceinline__ RayD make_ray(vec3 o, vec3 d)
@@ -75,35 +75,82 @@ __device__ __forceinline__ RayD make_ray(vec3 o, vec3 d)
     r.d = d;
     r.inv = make3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.zx = is_zero(d.x); r.zy = is_zero(d.y); r.zz = is_zero(d.z);
-    r.px = d.x > 0; r.py = d.y > 0; r.pz = d.z > 0;
+    return r;
+}
+
+// One 64-byte record as four 16-byte loads.
+struct Rec64 {
+    float4 a, b, c, d;
+};
+__device__ __forceinline__ Rec64 load_rec(const void* p)
+{
+    const float4* q = static_cast<const float4*>(p);
+    Rec64 r;
+    r.a = q[0];
+    r.b = q[1];
+    r.c = q[2];
+    r.d = q[3];
+    return r;
+}
+
+// One 64-byte record through the scalar data path, for addresses that are the same in every lane of the wave
+// (packet traversal): one s_load instead of 64 lanes x 4 vector loads, and the values land in SGPRs that the
+// box / triangle arithmetic reads as scalar operands.  Load only: the scalar cache is never written.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ Rec64 load_rec_uniform(const void* p)
+{
+    u32x16 v;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    Rec64 r;
+    r.a = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+    r.b = make_float4(__uint_as_float(v[4]), __uint_as_float(v[5]), __uint_as_float(v[6]), __uint_as_float(v[7]));
+    r.c = make_float4(__uint_as_float(v[8]), __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]));
+    r.d = make_float4(__uint_as_float(v[12]), __uint_as_float(v[13]), __uint_as_float(v[14]), __uint_as_float(v[15]));
     return r;
 }
 
 // Ray/box test of reference src/intersect.cpp:111-140 without the final comparison against ray.t: returns
 // whether the box is entered at all and the parameter the reference would report (t_out when the origin is
 // inside).  The caller compares against its own bound.
-__device__ __forceinline__ bool box_entry(const RayD& r, const float* lo, const float* hi, float& tBox)
+//
+// The reference picks the near and far plane of each slab by the sign of the direction component.  Because
+// lo <= hi and multiplication by the (same-signed) reciprocal is monotonic, the near value is the smaller
+// and the far value the larger of the two products, so min/max select the same numbers; none of them can
+// be NaN (the |d| <= 1e-6 case is overridden with -/+FLT_MAX exactly as in the reference), so the hardware
+// min/max agree with glm's comparison-based ones.
+__device__ __forceinline__ bool box_entry(const RayD& r, float lx, float ly, float lz, float hx, float hy, float hz, float& tBox)
 {
-    float t0 = r.zx ? -FLT_MAX : ((r.px ? lo[0] : hi[0]) - r.o.x) * r.inv.x;
-    float t1 = r.zx ? FLT_MAX : ((r.px ? hi[0] : lo[0]) - r.o.x) * r.inv.x;
-    float t2 = r.zy ? -FLT_MAX : ((r.py ? lo[1] : hi[1]) - r.o.y) * r.inv.y;
-    float t3 = r.zy ? FLT_MAX : ((r.py ? hi[1] : lo[1]) - r.o.y) * r.inv.y;
-    float t4 = r.zz ? -FLT_MAX : ((r.pz ? lo[2] : hi[2]) - r.o.z) * r.inv.z;
-    float t5 = r.zz ? FLT_MAX : ((r.pz ? hi[2] : lo[2]) - r.o.z) * r.inv.z;
-    float tin = sel_max(sel_max(t0, t2), t4);
-    float tout = sel_min(sel_min(t1, t3), t5);
+    const float ax = (lx - r.o.x) * r.inv.x, bx = (hx - r.o.x) * r.inv.x;
+    const float ay = (ly - r.o.y) * r.inv.y, by = (hy - r.o.y) * r.inv.y;
+    const float az = (lz - r.o.z) * r.inv.z, bz = (hz - r.o.z) * r.inv.z;
+    const float t0 = r.zx ? -FLT_MAX : fminf(ax, bx), t1 = r.zx ? FLT_MAX : fmaxf(ax, bx);
+    const float t2 = r.zy ? -FLT_MAX : fminf(ay, by), t3 = r.zy ? FLT_MAX : fmaxf(ay, by);
+    const float t4 = r.zz ? -FLT_MAX : fminf(az, bz), t5 = r.zz ? FLT_MAX : fmaxf(az, bz);
+    const float tin = fmaxf(fmaxf(t0, t2), t4);
+    const float tout = fminf(fminf(t1, t3), t5);
     if (tin > tout || tout <= 0 || is_zero(tin)) return false;
     tBox = tin < 0 ? tout : tin;
     return true;
 }
+__device__ __forceinline__ bool box_entry(const RayD& r, const float* lo, const float* hi, float& tBox)
+{
+    return box_entry(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tBox);
+}
+// the two child boxes of a node record loaded with load_rec (field order of NodeRec)
+__device__ __forceinline__ bool box_entry_left(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, t); }
+__device__ __forceinline__ bool box_entry_right(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, t); }
+__device__ __forceinline__ int32_t node_ref_left(const Rec64& n) { return __float_as_int(n.d.x); }
+__device__ __forceinline__ int32_t node_ref_right(const Rec64& n) { return __float_as_int(n.d.y); }
 
 // Ray/triangle test of reference src/intersect.cpp:22-80 on a precomputed record.  `tmax` is the current
 // closest distance; returns true and the new distance when the triangle is accepted.  The rejections are
 // evaluated cheapest-first; each is a pure predicate, so the order does not change the outcome.
-__device__ __forceinline__ bool triangle_hit(const RayD& r, const PrimRec& p, float tmax, float& tHit)
+__device__ __forceinline__ bool triangle_hit(const RayD& r, const Rec64& p, float tmax, float& tHit)
 {
-    const vec3 n = load3(p.n);
-    const vec3 v0 = load3(p.v0);
+    // field order of PrimRec: v0, v1, v2, n, invArea, more, mesh, prim
+    const vec3 v0 = make3(p.a.x, p.a.y, p.a.z), v1 = make3(p.a.w, p.b.x, p.b.y), v2 = make3(p.b.z, p.b.w, p.c.x);
+    const vec3 n = make3(p.c.y, p.c.z, p.c.w);
+    const float invArea = p.d.x;
     const float dn = dot(n, r.d);
     if (is_zero(dn)) return false;
     const float D = dot(n, v0);
@@ -112,14 +159,14 @@ __device__ __forceinline__ bool triangle_hit(const RayD& r, const PrimRec& p, fl
     if (!(t < tmax)) return false;
     const vec3 pt = r.o + r.d * t;
     if (!is_zero(dot(n, pt - v0))) return false;
-    const vec3 v1 = load3(p.v1), v2 = load3(p.v2);
-    const float alpha = length(cross(pt - v2, v1 - v2)) * p.invArea;
-    const float beta = length(cross(pt - v2, v0 - v2)) * p.invArea;
-    const float gamma = length(cross(pt - v1, v0 - v1)) * p.invArea;
+    const float alpha = length(cross(pt - v2, v1 - v2)) * invArea;
+    const float beta = length(cross(pt - v2, v0 - v2)) * invArea;
+    const float gamma = length(cross(pt - v1, v0 - v1)) * invArea;
     if (alpha < 0 || beta < 0 || alpha + beta > 1.0f || alpha + gamma > 1.0f || beta + gamma > 1.0f) return false;
     tHit = t;
     return true;
 }
+__device__ __forceinline__ int32_t prim_more(const Rec64& p) { return __float_as_int(p.d.y); }
 
 // LDS traversal stack of one lane.  Entry e of lane l sits at base[e * blockDim + l].
 struct Stack {
@@ -163,12 +210,12 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
             bool descend = true;
             if (PRUNE) descend = !(curT > (hit >= 0 ? tmax : FLT_MAX));
             if (descend) {
-                const NodeRec& nd = S.nodes[cur];
+                const Rec64 nd = load_rec(&S.nodes[cur]);
                 float tL, tR;
                 if (COUNT) cnt.box += 2;
-                const bool vL = box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
-                const bool vR = box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
-                const int32_t refL = nd.refL, refR = nd.refR;
+                const bool vL = box_entry_left(r, nd, tL) && tL < FLT_MAX;
+                const bool vR = box_entry_right(r, nd, tR) && tR < FLT_MAX;
+                const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
                 if (vL && vR) {
                     const bool leftFirst = tL < tR;
                     st.push(sp++, leftFirst ? refR : refL, leftFirst ? tR : tL);
@@ -192,8 +239,8 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
             int32_t slot = ~cur;
             int32_t more;
             do {
-                const PrimRec& p = S.prims[slot];
-                more = p.more;
+                const Rec64 p = load_rec(&S.prims[slot]);
+                more = prim_more(p);
                 if (COUNT) cnt.tri++;
                 float t;
                 if (triangle_hit(r, p, tmax, t)) {
@@ -217,7 +264,7 @@ __device__ int brute_force(const SceneView& S, const RayD& r, float& tmax, Count
     int hit = -1;
     for (int i = 0; i < S.numPrims; i++) {
         const int slot = int(S.primOrder[i]);
-        const PrimRec& p = S.prims[slot];
+        const Rec64 p = load_rec(&S.prims[slot]);
         if (COUNT) cnt.tri++;
         float t;
         if (triangle_hit(r, p, tmax, t)) {

@@ -143,140 +143,128 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
 }
 
 // Shadow pass: one any-hit query per (queued hit, shadow-casting light sample) — testVisibilityLightSample,
-// reference src/light.cpp:68-89 — traced as PACKETS of 16 rays, one packet per 16-lane row of the wave.
+// reference src/light.cpp:68-89 — traced as wave-wide PACKETS of 64 rays.
 //
-// Work item w = hit * samplesPerHit + j; packet p holds items 16p .. 16p+15, i.e. the shadow rays of one hit
-// point towards one area light (or of neighbouring hits towards a point light): nearly identical rays.  The
-// 16 lanes of a row walk the hierarchy together with ONE shared stack and fetch the same node record, so a
-// node costs one cache-line access per packet instead of one per ray.
+// Work item w = hit * samplesPerHit + j; packet p holds items 64p .. 64p+63: the shadow rays of a few
+// neighbouring hit points towards one area light (or of an 8x8 pixel tile towards a point light), i.e.
+// nearly identical rays.  The whole wave walks the hierarchy together: ONE stack, ONE current node, whose
+// record is fetched with scalar loads (it is the same address for all lanes) and whose two boxes every lane
+// tests against its own ray.  Control flow is wave-uniform; only the per-lane "is my ray in this node" bit
+// varies.
 //
-// This is exact, not an approximation: each stack entry carries the 16-bit set of rays that entered that
+// This is exact, not an approximation: each stack entry carries the 64-bit set of rays that entered that
 // node through box tests of their own, a ray only tests the primitives of leaves it is in, and the answer of
 // an any-hit query ("is any primitive accepted before the light") does not depend on the order in which the
 // nodes a ray enters are visited.  So every ray performs exactly the box and primitive tests the reference's
 // traversal would make for it until its first accepted primitive, and gets the same boolean.
 //
-// Persistent waves: a row whose packet has ended takes the next one from a global cursor; every row stops
-// once the cursor has passed the packet count.
+// Persistent waves: a wave whose packet has ended takes the next one from a global cursor and stops once
+// the cursor has passed the packet count.
+struct PacketEntry {
+    int32_t ref;
+    uint32_t pad;
+    unsigned long long mask;
+};
+
 template <bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
 {
-    __shared__ uint2 packetStack[4][RT_MAX_LEVELS + 1];
+    __shared__ PacketEntry stack[RT_MAX_LEVELS + 1];
     const int lane = int(threadIdx.x);
-    const int row = lane >> 4, col = lane & 15;
     Counts cnt;
     const SceneView& S = P.scene;
     const unsigned long long perHit = (unsigned long long)P.shadowSamplesPerHit;
     const unsigned long long total = P.queueCounters[0] * perHit;
-    const unsigned long long nPackets = (total + 15ull) / 16ull;
+    const unsigned long long nPackets = (total + 63ull) / 64ull;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
-    auto row_mask = [&](bool pred) -> uint32_t { return uint32_t((__ballot(pred) >> (16 * row)) & 0xffffull); };
-    uint2* stack = packetStack[row];
-    bool idle = true, finished = false; // uniform within a row
-    RayD r;
-    bool traced = false, blocked = false; // this lane's ray passed the root gate / has been found occluded
-    unsigned long long work = 0;
-    uint32_t alive = 0, mask = 0;         // uniform within a row: rays still undecided / rays inside `cur`
-    int32_t cur = 0;
-    int sp = 0;
     while (true) {
-        if (idle && !finished) {
-            unsigned long long pk = 0;
-            if (col == 0) pk = atomicAdd(&P.queueCounters[1], 1ull);
-            pk = __shfl(pk, row * 16, 64);
-            if (pk >= nPackets) {
-                finished = true;
-            } else {
-                work = pk * 16ull + (unsigned long long)col;
-                traced = false;
-                blocked = false;
-                if (work < total) {
-                    const HitEntry e = P.queue[work / perHit];
-                    const int j = int(work % perHit);
-                    Rng rng;
-                    RayD cam;
-                    size_t pix;
-                    int sidx;
-                    hit_ray(P, e, nPix, rng, cam, pix, sidx);
-                    // which light and which of its samples: the last light whose first shadow sample is <= j
-                    int li = 0;
-                    for (int i = 0; i < P.nLights; i++)
-                        if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
-                    const LightDev& L = P.lights[li];
-                    const int k = j - L.shadowBase;
-                    vec3 position, color;
-                    light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
-                    const float epsilon = 0.00001f;
-                    const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
-                    r = make_ray(origin, position - origin);
-                    cnt.shadow++;
-                    float tRoot;
-                    if (COUNT) cnt.box++;
-                    // root gate against the shadow ray's own bound t = 1 (…hierarchy.cpp:296-301)
-                    traced = box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f;
-                    if (!traced) P.visibility[work] = 1;
-                }
-                alive = row_mask(traced);
-                if (alive) {
-                    idle = false;
-                    cur = S.rootRef;
-                    mask = alive;
-                    sp = 0;
-                }
-            }
+        unsigned long long pk = 0;
+        if (lane == 0) pk = atomicAdd(&P.queueCounters[1], 1ull);
+        pk = __shfl(pk, 0, 64);
+        if (pk >= nPackets) break;
+        const unsigned long long work = pk * 64ull + (unsigned long long)lane;
+        RayD r = make_ray(splat3(0.0f), splat3(1.0f));
+        bool traced = false;
+        if (work < total) {
+            const HitEntry e = P.queue[work / perHit];
+            const int j = int(work % perHit);
+            Rng rng;
+            RayD cam;
+            size_t pix;
+            int sidx;
+            hit_ray(P, e, nPix, rng, cam, pix, sidx);
+            // which light and which of its samples: the last light whose first shadow sample is <= j
+            int li = 0;
+            for (int i = 0; i < P.nLights; i++)
+                if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
+            const LightDev& L = P.lights[li];
+            const int k = j - L.shadowBase;
+            vec3 position, color;
+            light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+            const float epsilon = 0.00001f;
+            const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
+            r = make_ray(origin, position - origin);
+            cnt.shadow++;
+            float tRoot;
+            if (COUNT) cnt.box++;
+            // root gate against the shadow ray's own bound t = 1 (…hierarchy.cpp:296-301)
+            traced = box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f;
         }
-        if (!__ballot(!idle)) {
-            if (!__ballot(!finished)) break;
-            continue;
-        }
-        if (!idle) {
-            const uint32_t in = mask & alive;
-            const bool mine = (in >> col) & 1u;
+        bool blocked = false;
+        unsigned long long alive = __ballot(traced); // rays still undecided
+        unsigned long long mask = alive;             // rays inside `cur`
+        int32_t cur = S.rootRef;
+        int sp = 0;
+        while (alive) {
+            const unsigned long long in = mask & alive;
             bool descend = false;
             if (in) {
+                const bool mine = (in >> lane) & 1ull;
                 if (cur >= 0) {
-                    const NodeRec& nd = S.nodes[cur];
+                    const Rec64 nd = load_rec_uniform(&S.nodes[__builtin_amdgcn_readfirstlane(cur)]);
                     float tL, tR;
                     if (COUNT && mine) cnt.box += 2;
-                    const bool vL = mine && box_entry(r, nd.loL, nd.hiL, tL) && tL < FLT_MAX;
-                    const bool vR = mine && box_entry(r, nd.loR, nd.hiR, tR) && tR < FLT_MAX;
-                    const uint32_t mL = row_mask(vL), mR = row_mask(vR);
-                    const int32_t refL = nd.refL, refR = nd.refR;
-                    if (mL && mR) {
-                        if (col == 0) stack[sp] = make_uint2(uint32_t(refR), mR);
-                        sp++;
-                    }
+                    const bool vL = mine && box_entry_left(r, nd, tL) && tL < FLT_MAX;
+                    const bool vR = mine && box_entry_right(r, nd, tR) && tR < FLT_MAX;
+                    const unsigned long long mL = __ballot(vL), mR = __ballot(vR);
+                    const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
                     if (mL | mR) {
-                        cur = mL ? refL : refR;
-                        mask = mL ? mL : mR;
+                        // visit the child more rays are in first; park the other one
+                        const bool leftFirst = mR == 0 || (mL != 0 && __popcll(mL) >= __popcll(mR));
+                        if (mL && mR) {
+                            if (lane == 0) {
+                                stack[sp].ref = leftFirst ? refR : refL;
+                                stack[sp].mask = leftFirst ? mR : mL;
+                            }
+                            sp++;
+                        }
+                        cur = leftFirst ? refL : refR;
+                        mask = leftFirst ? mL : mR;
                         descend = true;
                     }
                 } else {
-                    int32_t slot = ~cur;
+                    int32_t slot = __builtin_amdgcn_readfirstlane(~cur);
                     int32_t more;
                     do {
-                        const PrimRec& p = S.prims[slot];
-                        more = p.more;
+                        const Rec64 p = load_rec_uniform(&S.prims[slot]);
+                        more = prim_more(p);
                         const bool test = mine && !blocked;
                         if (COUNT && test) cnt.tri++;
                         float t;
                         if (test && triangle_hit(r, p, 1.0f, t)) blocked = true;
                         slot++;
                     } while (more > 0);
-                    alive &= ~row_mask(blocked);
+                    alive &= ~__ballot(blocked);
                 }
             }
             if (!descend) {
-                if (sp == 0 || alive == 0) {
-                    if (traced) P.visibility[work] = blocked ? 0 : 1;
-                    idle = true;
-                } else {
-                    const uint2 e = stack[--sp];
-                    cur = int32_t(e.x);
-                    mask = e.y;
-                }
+                if (sp == 0) break;
+                --sp;
+                cur = stack[sp].ref;
+                mask = stack[sp].mask;
             }
         }
+        if (work < total) P.visibility[work] = (traced && blocked) ? 0 : 1;
     }
     flush_counts(cnt, P.stats);
 }
