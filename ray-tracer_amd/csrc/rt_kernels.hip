@@ -232,10 +232,8 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
                         // visit the child more rays are in first; park the other one
                         const bool leftFirst = mR == 0 || (mL != 0 && __popcll(mL) >= __popcll(mR));
                         if (mL && mR) {
-                            if (lane == 0) {
-                                stack[sp].ref = leftFirst ? refR : refL;
-                                stack[sp].mask = leftFirst ? mR : mL;
-                            }
+                            stack[sp].ref = leftFirst ? refR : refL; // same value from every lane
+                            stack[sp].mask = leftFirst ? mR : mL;
                             sp++;
                         }
                         cur = leftFirst ? refL : refR;
