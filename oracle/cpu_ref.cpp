@@ -227,14 +227,16 @@ bool intersectTriangle(V3 v0, V3 v1, V3 v2, Ray& ray, HitInfo& hit)
 // intersect.cpp:84-107
 bool intersectSphere(const Sphere& s, Ray& ray, HitInfo& hit)
 {
+    // The unqualified pow(...) and sqrt(...) of the reference resolve to the C double functions, so the
+    // expressions they appear in are evaluated in double and narrowed on assignment.
     float a = dot(ray.d, ray.d);
     float b = 2.0f * dot(ray.d, ray.o - s.c);
-    float c = dot(ray.o - s.c, ray.o - s.c) - float(std::pow(double(s.r), double(2.0f)));
+    float c = float(double(dot(ray.o - s.c, ray.o - s.c)) - std::pow(double(s.r), double(2.0f)));
     float D = b * b - 4 * a * c;
     if (D < 0 || isZero(c))
         return false;
-    float t1 = (-b - std::sqrt(D)) / (2 * a);
-    float t2 = (-b + std::sqrt(D)) / (2 * a);
+    float t1 = float((double(-b) - std::sqrt(double(D))) / double(2 * a));
+    float t2 = float((double(-b) + std::sqrt(double(D))) / double(2 * a));
     if (t1 < 0 && t2 < 0)
         return false;
     float newT = t1 * t2 < 0 ? std::fmax(t1, t2) : std::fmin(t1, t2);

@@ -235,6 +235,7 @@ struct Cam {
 };
 static const Cam CAM_A { 50.0f, 3.0f, { 0.0f, 0.0f, 0.0f }, { 20.0f, 20.0f, 0.0f } }; // src/config.h:16-21
 static const Cam CAM_B { 60.0f, 2.5f, { 0.1f, -0.05f, 0.05f }, { -15.0f, 140.0f, 0.0f } };
+static const Cam CAM_S { 70.0f, 3.0f, { 0.0f, 0.0f, 4.0f }, { 10.0f, 15.0f, 0.0f } }; // looks down +z at the Spheres scene
 
 struct CamState {
     glm::vec3 euler, lookAt;
@@ -783,7 +784,7 @@ int main(int argc, char** argv)
         { "cube_segment", Cube }, { "cube_textured", CubeTextured }, { "cornell", CornellBox },
         { "cornell_para", CornellBoxParallelogramLight }, { "monkey", Monkey }, { "teapot", Teapot },
         { "quad_textured", QuadTextured }, { "transparent_cubes", TransparentCubes }, { "transparent_cornell", TransparentCornell },
-        { "single_triangle", SingleTriangle },
+        { "single_triangle", SingleTriangle }, { "spheres", Spheres },
     };
 
     dump_kats();

@@ -346,8 +346,6 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
     if (options) opt = *options;
     if (opt.max_level < 0 || opt.max_level > RT_MAX_LEVELS - 1) return fail(RT_ERR_LIMIT, "max_level must be in [0, 32]");
     if (opt.sah_binning && opt.sah_bins < 1) return fail(RT_ERR_INVALID, "sah_bins must be positive");
-    if (!scene->host.spheres.empty())
-        return fail(RT_ERR_INVALID, "sphere primitives are not supported by the kernels yet");
     rt_bvh* b = new (std::nothrow) rt_bvh;
     if (!b) return fail(RT_ERR_INVALID, "out of host memory");
     b->scene = scene;

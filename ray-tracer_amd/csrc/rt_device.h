@@ -167,6 +167,40 @@ __device__ __forceinline__ bool triangle_hit(const RayD& r, const Rec64& p, floa
     return true;
 }
 __device__ __forceinline__ int32_t prim_more(const Rec64& p) { return __float_as_int(p.d.y); }
+__device__ __forceinline__ int32_t prim_mesh(const Rec64& p) { return __float_as_int(p.d.z); }
+
+// Ray/sphere test of reference src/intersect.cpp:84-107 on a PrimRec (v0 = centre, v1[0] = radius).  The
+// reference's unqualified pow() and sqrt() are the C double functions, so the radius term and the two roots
+// are evaluated in double and narrowed on assignment; reproduced here.  `wrote` reports that the reference
+// would have overwritten HitInfo::normal / material (it does so even when the sphere is not the closest hit).
+__device__ __forceinline__ bool sphere_hit(const RayD& r, const Rec64& p, float& tmax, bool& wrote)
+{
+    wrote = false;
+    const vec3 c = make3(p.a.x, p.a.y, p.a.z);
+    const float radius = p.a.w;
+    const vec3 oc = r.o - c;
+    const float a = dot(r.d, r.d);
+    const float b = 2.0f * dot(r.d, oc);
+    const float cc = float(double(dot(oc, oc)) - double(radius) * double(radius));
+    const float D = b * b - 4 * a * cc;
+    if (D < 0 || is_zero(cc)) return false;
+    const double root = sqrt(double(D));
+    const float t1 = float((double(-b) - root) / double(2 * a));
+    const float t2 = float((double(-b) + root) / double(2 * a));
+    if (t1 < 0 && t2 < 0) return false;
+    const float newT = t1 * t2 < 0 ? fmaxf(t1, t2) : fminf(t1, t2);
+    const bool valid = newT < tmax;
+    if (valid) tmax = newT;
+    wrote = true;
+    return valid;
+}
+
+// Which primitive last wrote HitInfo's normal/material and the ray distance at that moment.  Without spheres
+// this is simply the closest hit; a sphere test rewrites them even when it loses (see sphere_hit).
+struct Attr {
+    int slot;
+    float t;
+};
 
 // LDS traversal stack of one lane.  Entry e of lane l sits at base[e * blockDim + l].
 struct Stack {
@@ -191,9 +225,12 @@ struct Stack {
 //   - a triangle is accepted when strictly closer than the current distance, so ties keep the first found.
 // Returns the slot of the accepted primitive (or -1) and updates tmax.  An any-hit query returns at the
 // first accepted triangle: the reference's boolean is the same because acceptance is what sets it.
-template <bool PRUNE, bool ANY, bool COUNT>
-__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt)
+template <bool PRUNE, bool ANY, bool COUNT, bool SPH>
+__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt, Attr& attr)
 {
+    attr.slot = -1;
+    attr.t = tmax;
+    float bestTri = FLT_MAX; // the reference's absoluteT: only triangle hits lower it (…hierarchy.cpp:344-347)
     if (S.numPrims == 0) return -1;
     float tRoot;
     if (COUNT) cnt.box++;
@@ -208,7 +245,7 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
     while (true) {
         while (cur >= 0) {
             bool descend = true;
-            if (PRUNE) descend = !(curT > (hit >= 0 ? tmax : FLT_MAX));
+            if (PRUNE) descend = !(curT > (SPH ? bestTri : (hit >= 0 ? tmax : FLT_MAX)));
             if (descend) {
                 const Rec64 nd = load_rec(&S.nodes[cur]);
                 float tL, tR;
@@ -234,7 +271,7 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
         }
         if (cur == DONE) break;
         bool test = true;
-        if (PRUNE) test = !(curT > (hit >= 0 ? tmax : FLT_MAX));
+        if (PRUNE) test = !(curT > (SPH ? bestTri : (hit >= 0 ? tmax : FLT_MAX)));
         if (test) {
             int32_t slot = ~cur;
             int32_t more;
@@ -242,11 +279,26 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
                 const Rec64 p = load_rec(&S.prims[slot]);
                 more = prim_more(p);
                 if (COUNT) cnt.tri++;
-                float t;
-                if (triangle_hit(r, p, tmax, t)) {
-                    tmax = t;
-                    hit = slot;
-                    if (ANY) return hit;
+                if (SPH && prim_mesh(p) < 0) {
+                    bool wrote;
+                    if (sphere_hit(r, p, tmax, wrote)) {
+                        hit = slot;
+                        if (ANY) return hit;
+                    }
+                    if (wrote) {
+                        attr.slot = slot;
+                        attr.t = tmax;
+                    }
+                } else {
+                    float t;
+                    if (triangle_hit(r, p, tmax, t)) {
+                        tmax = t;
+                        bestTri = t;
+                        hit = slot;
+                        attr.slot = slot;
+                        attr.t = t;
+                        if (ANY) return hit;
+                    }
                 }
                 slot++;
             } while (more > 0);
@@ -258,29 +310,51 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
 }
 
 // Brute-force branch (reference src/bounding_volume_hierarchy.cpp:462-528): every triangle in mesh order.
-template <bool ANY, bool COUNT>
-__device__ int brute_force(const SceneView& S, const RayD& r, float& tmax, Counts& cnt)
+template <bool ANY, bool COUNT, bool SPH>
+__device__ int brute_force(const SceneView& S, const RayD& r, float& tmax, Counts& cnt, Attr& attr)
 {
     int hit = -1;
+    attr.slot = -1;
+    attr.t = tmax;
     for (int i = 0; i < S.numPrims; i++) {
         const int slot = int(S.primOrder[i]);
         const Rec64 p = load_rec(&S.prims[slot]);
         if (COUNT) cnt.tri++;
-        float t;
-        if (triangle_hit(r, p, tmax, t)) {
-            tmax = t;
-            hit = slot;
-            if (ANY) return hit;
+        if (SPH && prim_mesh(p) < 0) {
+            bool wrote;
+            if (sphere_hit(r, p, tmax, wrote)) {
+                hit = slot;
+                if (ANY) return hit;
+            }
+            if (wrote) {
+                attr.slot = slot;
+                attr.t = tmax;
+            }
+        } else {
+            float t;
+            if (triangle_hit(r, p, tmax, t)) {
+                tmax = t;
+                hit = slot;
+                attr.slot = slot;
+                attr.t = t;
+                if (ANY) return hit;
+            }
         }
     }
     return hit;
 }
 
-template <bool PRUNE, bool ANY, bool COUNT>
+template <bool PRUNE, bool ANY, bool COUNT, bool SPH = false>
+__device__ __forceinline__ int intersect(const FrameParams& P, const RayD& r, float& tmax, Stack st, Counts& cnt, Attr& attr)
+{
+    if (!P.f.accel_structure) return brute_force<ANY, COUNT, SPH>(P.scene, r, tmax, cnt, attr);
+    return traverse<PRUNE, ANY, COUNT, SPH>(P.scene, r, tmax, st, cnt, attr);
+}
+template <bool PRUNE, bool ANY, bool COUNT, bool SPH = false>
 __device__ __forceinline__ int intersect(const FrameParams& P, const RayD& r, float& tmax, Stack st, Counts& cnt)
 {
-    if (!P.f.accel_structure) return brute_force<ANY, COUNT>(P.scene, r, tmax, cnt);
-    return traverse<PRUNE, ANY, COUNT>(P.scene, r, tmax, st, cnt);
+    Attr attr;
+    return intersect<PRUNE, ANY, COUNT, SPH>(P, r, tmax, st, cnt, attr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -337,6 +411,18 @@ __device__ __forceinline__ Surface surface_at(const FrameParams& P, const RayD& 
     const SceneView& S = P.scene;
     const PrimRec& p = S.prims[slot];
     Surface s;
+    if (p.mesh < 0) {
+        // sphere: HitInfo::normal = point - centre, unnormalised (intersect.cpp:103); `t` is the ray distance
+        // at the moment the sphere test wrote it
+        const MaterialRec& m = S.mats[S.numMeshes + p.prim];
+        s.normal = -load3(p.v0) + (r.d * t + r.o);
+        s.bary = splat3(0.0f);
+        s.kd = load3(m.kd);
+        s.ks = load3(m.ks);
+        s.shininess = m.shininess;
+        s.transparency = m.transparency;
+        return s;
+    }
     const vec3 v0 = load3(p.v0), v1 = load3(p.v1), v2 = load3(p.v2);
     const vec3 point = r.o + r.d * t;
     s.normal = load3(p.n);
@@ -434,7 +520,7 @@ __device__ __forceinline__ vec3 phong(vec3 lightPos, vec3 lightColor, const RayD
 }
 
 // reference src/light.cpp:68-89
-template <bool PRUNE, bool COUNT>
+template <bool PRUNE, bool COUNT, bool SPH = false>
 __device__ __forceinline__ float visibility(const FrameParams& P, vec3 samplePos, const RayD& r, float t, Stack st, Counts& cnt)
 {
     const float epsilon = 0.00001f;
@@ -442,7 +528,7 @@ __device__ __forceinline__ float visibility(const FrameParams& P, vec3 samplePos
     const RayD shadow = make_ray(origin, samplePos - origin);
     float tmax = 1.0f;
     cnt.shadow++;
-    return intersect<PRUNE, true, COUNT>(P, shadow, tmax, st, cnt) >= 0 ? 0.0f : 1.0f;
+    return intersect<PRUNE, true, COUNT, SPH>(P, shadow, tmax, st, cnt) >= 0 ? 0.0f : 1.0f;
 }
 
 // Sample k of light L (reference src/light.cpp:22-64 with the loop bookkeeping of :160-167,195-201): position
@@ -489,7 +575,7 @@ __device__ __forceinline__ vec3 light_weight(const LightDev& L, vec3 shade)
 
 // reference src/light.cpp:124-220.  All light types run through one sample loop so the kernel holds a single
 // copy of the shadow-ray traversal and of the Phong term.
-template <bool PRUNE, bool COUNT>
+template <bool PRUNE, bool COUNT, bool SPH = false>
 __device__ vec3 light_contribution(const FrameParams& P, const RayD& r, float t, const Surface& s, Rng& rng, Stack st, Counts& cnt)
 {
     vec3 shading = splat3(0.0f);
@@ -503,7 +589,7 @@ __device__ vec3 light_contribution(const FrameParams& P, const RayD& r, float t,
             vec3 position, color;
             light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter, position, color);
             rng.randCounter += per;
-            const float lighted = shadowed ? visibility<PRUNE, COUNT>(P, position, r, t, st, cnt) : 1.0f;
+            const float lighted = shadowed ? visibility<PRUNE, COUNT, SPH>(P, position, r, t, st, cnt) : 1.0f;
             const vec3 shade = P.f.shading ? phong(position, color, r, t, s) : s.kd;
             shading = shading + light_weight(L, shade) * lighted;
         }
@@ -534,7 +620,7 @@ struct GlossyFrame {
     int32_t next, call, depth;
 };
 
-template <bool PRUNE, bool GLOSSY, bool COUNT>
+template <bool PRUNE, bool GLOSSY, bool COUNT, bool SPH>
 __device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, Rng& rng, Stack st, Counts& cnt, float& firstT)
 {
     bool first = true;
@@ -548,7 +634,8 @@ __device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, R
     while (true) {
         if (state == TRACE) {
             float t = FLT_MAX;
-            const int slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
+            Attr attr;
+            const int slot = intersect<PRUNE, false, COUNT, SPH>(P, r, t, st, cnt, attr);
             state = RETURN;
             if (first) {
                 firstT = t;
@@ -558,7 +645,7 @@ __device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, R
                 result = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
                 continue;
             }
-            const Surface s = surface_at(P, r, t, slot);
+            const Surface s = surface_at(P, r, attr.t, attr.slot);
             const bool reflMap = P.f.environment_mapping && P.p.enabled_refl_map;
             const bool blend = !reflMap && P.f.transparency && s.transparency != 1.0f;
             const bool specular = !reflMap && !blend && (P.f.recursive || P.f.glossy) && depth > 0 && (s.ks.x != 0 || s.ks.y != 0 || s.ks.z != 0);
@@ -567,7 +654,7 @@ __device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, R
             // here but still consume the same random draws, so later draws keep their indices.
             vec3 Lo = splat3(0.0f);
             if (reflMap || specular) rng.randCounter += uint32_t(P.drawsPerHit);
-            else Lo = light_contribution<PRUNE, COUNT>(P, r, t, s, rng, st, cnt);
+            else Lo = light_contribution<PRUNE, COUNT, SPH>(P, r, t, s, rng, st, cnt);
             if (reflMap) {
                 result = skybox_color(P.scene, r.d);
             } else if (blend) {
@@ -686,7 +773,7 @@ __device__ __forceinline__ void camera_ray(const FrameParams& P, float px, float
 //   depth of field on -> sample 0 is the centre ray (whose first hit distance doubles as the reference's
 //                        probe query, render.cpp:106-110: same ray, same traversal), samples 1.. the lens rays;
 //   otherwise         -> the single camera ray.
-template <bool PRUNE, bool GLOSSY, bool COUNT>
+template <bool PRUNE, bool GLOSSY, bool COUNT, bool SPH>
 __device__ vec3 render_sample(const FrameParams& P, int x, int y, int sidx, Stack st, Counts& cnt, bool& dofFlag)
 {
     Rng rng;
@@ -727,7 +814,7 @@ __device__ vec3 render_sample(const FrameParams& P, int x, int y, int sidx, Stac
     cnt.primary++;
     const float dlen = length(d);
     float firstT;
-    const vec3 color = final_color<PRUNE, GLOSSY, COUNT>(P, o, d, rng, st, cnt, firstT);
+    const vec3 color = final_color<PRUNE, GLOSSY, COUNT, SPH>(P, o, d, rng, st, cnt, firstT);
     dofFlag = firstT != FLT_MAX && fabsf(P.p.dof_f - dlen * firstT) > P.p.dof;
     return color;
 }

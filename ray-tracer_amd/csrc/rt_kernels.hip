@@ -61,7 +61,7 @@ __device__ __forceinline__ LaneId lane_id(const FrameParams& P)
 }
 
 // General path: the whole evaluation of a sample (any feature combination) in one lane.
-template <bool PRUNE, bool GLOSSY, bool COUNT>
+template <bool PRUNE, bool GLOSSY, bool COUNT, bool SPH>
 __global__ void __launch_bounds__(WAVE) k_render(const FrameParams P)
 {
     extern __shared__ uint2 lds_stack[];
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(WAVE) k_render(const FrameParams P)
         if (P.f.depth_of_field && id.sidx > 0) live = P.dofFlags[id.pix] != 0;
         if (live) {
             bool dofFlag = false;
-            const vec3 c = render_sample<PRUNE, GLOSSY, COUNT>(P, id.x, id.y, id.sidx, st, cnt, dofFlag);
+            const vec3 c = render_sample<PRUNE, GLOSSY, COUNT, SPH>(P, id.x, id.y, id.sidx, st, cnt, dofFlag);
             float* o = sample_slot(P, id.pix, id.sidx);
             o[0] = c.x;
             o[1] = c.y;
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(BLOCK) k_resolve(const FrameParams P)
     P.out[pix * 3 + 2] = color.z;
 }
 
-template <bool PRUNE>
+template <bool PRUNE, bool SPH>
 __global__ void __launch_bounds__(BLOCK) k_intersect(const FrameParams P, const rt_ray* __restrict__ rays, uint64_t n, rt_hit* __restrict__ hits)
 {
     extern __shared__ uint2 lds_stack[];
@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(BLOCK) k_intersect(const FrameParams P, const 
         const rt_ray ray = rays[i];
         const RayD r = make_ray(load3(ray.origin), load3(ray.direction));
         float t = ray.t;
-        const int slot = intersect<PRUNE, false, true>(P, r, t, st, cnt);
+        Attr attr;
+        const int slot = intersect<PRUNE, false, true, SPH>(P, r, t, st, cnt, attr);
         rt_hit h;
         h.hit = slot >= 0;
         h.t = t;
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect(const FrameParams P, const 
         h.kd[0] = h.kd[1] = h.kd[2] = 0.0f;
         if (slot >= 0) {
             const PrimRec& p = P.scene.prims[slot];
-            const Surface s = surface_at(P, r, t, slot);
+            const Surface s = surface_at(P, r, attr.t, attr.slot);
             h.mesh = p.mesh;
             h.triangle = p.prim;
             h.normal[0] = s.normal.x; h.normal[1] = s.normal.y; h.normal[2] = s.normal.z;
@@ -361,7 +362,7 @@ __global__ void __launch_bounds__(BLOCK) k_intersect(const FrameParams P, const 
     flush_counts(cnt, P.stats);
 }
 
-template <bool PRUNE>
+template <bool PRUNE, bool SPH>
 __global__ void __launch_bounds__(BLOCK) k_visibility(const FrameParams P, const rt_ray* __restrict__ rays, uint64_t n, const float* __restrict__ samples, int nSamples, uint8_t* __restrict__ out)
 {
     extern __shared__ uint2 lds_stack[];
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(BLOCK) k_visibility(const FrameParams P, const
         const int si = int(i % uint64_t(nSamples));
         const rt_ray ray = rays[ri];
         const RayD r = make_ray(load3(ray.origin), load3(ray.direction));
-        out[i] = visibility<PRUNE, false>(P, load3(samples + 3 * si), r, ray.t, st, cnt) != 0.0f ? 1 : 0;
+        out[i] = visibility<PRUNE, false, SPH>(P, load3(samples + 3 * si), r, ray.t, st, cnt) != 0.0f ? 1 : 0;
     }
 }
 
@@ -418,8 +419,13 @@ size_t stack_bytes(const FrameParams& P, int threads)
 template <bool PRUNE, bool GLOSSY>
 hipError_t launch_render_t(const FrameParams& P, dim3 grid, size_t lds, hipStream_t stream)
 {
-    if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true>), grid, dim3(WAVE), lds, stream, P);
-    else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false>), grid, dim3(WAVE), lds, stream, P);
+    if (P.scene.hasSpheres) {
+        if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true, true>), grid, dim3(WAVE), lds, stream, P);
+        else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false, true>), grid, dim3(WAVE), lds, stream, P);
+    } else {
+        if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true, false>), grid, dim3(WAVE), lds, stream, P);
+        else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false, false>), grid, dim3(WAVE), lds, stream, P);
+    }
     return hipGetLastError();
 }
 
@@ -467,7 +473,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     const size_t lds = stack_bytes(P, WAVE);
     const bool prune = !P.f.recursive && !P.f.transparency;
     const bool glossy = P.f.glossy != 0;
-    const bool split = P.queue != nullptr && P.f.accel_structure && direct_only(P);
+    const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P);
     hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         P.sampleBegin = sBegin;
@@ -510,8 +516,14 @@ hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n
     if (n == 0) return hipSuccess;
     const dim3 grid(uint32_t((n + BLOCK - 1) / BLOCK));
     const size_t lds = stack_bytes(P, BLOCK);
-    if (!P.f.recursive && !P.f.transparency) hipLaunchKernelGGL(k_intersect<true>, grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
-    else hipLaunchKernelGGL(k_intersect<false>, grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+    const bool prune = !P.f.recursive && !P.f.transparency;
+    if (P.scene.hasSpheres) {
+        if (prune) hipLaunchKernelGGL((k_intersect<true, true>), grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+        else hipLaunchKernelGGL((k_intersect<false, true>), grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+    } else {
+        if (prune) hipLaunchKernelGGL((k_intersect<true, false>), grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+        else hipLaunchKernelGGL((k_intersect<false, false>), grid, dim3(BLOCK), lds, stream, P, rays, n, hits);
+    }
     return hipGetLastError();
 }
 
@@ -521,8 +533,14 @@ hipError_t launch_visibility(const FrameParams& P, const rt_ray* rays, uint64_t 
     if (total == 0) return hipSuccess;
     const dim3 grid(uint32_t((total + BLOCK - 1) / BLOCK));
     const size_t lds = stack_bytes(P, BLOCK);
-    if (!P.f.recursive && !P.f.transparency) hipLaunchKernelGGL(k_visibility<true>, grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
-    else hipLaunchKernelGGL(k_visibility<false>, grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+    const bool prune = !P.f.recursive && !P.f.transparency;
+    if (P.scene.hasSpheres) {
+        if (prune) hipLaunchKernelGGL((k_visibility<true, true>), grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+        else hipLaunchKernelGGL((k_visibility<false, true>), grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+    } else {
+        if (prune) hipLaunchKernelGGL((k_visibility<true, false>), grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+        else hipLaunchKernelGGL((k_visibility<false, false>), grid, dim3(BLOCK), lds, stream, P, rays, n, samples, nSamples, out);
+    }
     return hipGetLastError();
 }
 

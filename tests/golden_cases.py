@@ -5,7 +5,7 @@ import importlib
 rt = importlib.import_module("ray-tracer_amd")
 
 SCENES = ["cube_segment", "cube_textured", "cornell", "cornell_para", "monkey", "teapot", "quad_textured",
-          "transparent_cubes", "transparent_cornell", "single_triangle"]
+          "transparent_cubes", "transparent_cornell", "single_triangle", "spheres"]
 B_SCENES = ["cornell", "monkey", "teapot", "transparent_cubes"]
 GLOSSY_SCENES = ["cornell", "transparent_cornell", "monkey"]
 

@@ -17,7 +17,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
-        if not os.path.exists(path):
+        src = os.path.join(ROOT, "oracle", "cpu_ref.cpp")
+        if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
         l = C.CDLL(path)
         l.orc_scene_create.restype = C.c_void_p
