@@ -31,7 +31,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 1920, 1080
-ROW_BLOCK = 16
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak
 CAMERA = dict(fov_deg=50.0, distance=3.0, look_at=(0.0, 0.0, 0.0), rot_deg=(20.0, 20.0, 0.0))  # reference src/config.h:16-21
@@ -73,6 +72,7 @@ def main():
 
     rt = importlib.import_module("ray-tracer_amd")
     synth = importlib.import_module("ray-tracer_amd.synth")
+    tiling = importlib.import_module("ray-tracer_amd.tiling")
     lib = rt.Library()  # raises when librt_amd.so is missing: there is no fallback path
     lib.init(local_rank)
 
@@ -85,33 +85,31 @@ def main():
     feats = rt.features(shading=1, soft_shadow=1, multiple_rays=1)
     params = rt.default_params(ray_multiplier=4)
 
-    # interleaved 16-row blocks, block b belongs to rank b % world
-    n_blocks = (HEIGHT + ROW_BLOCK - 1) // ROW_BLOCK
-    per_rank = (n_blocks + world - 1) // world
-    my_blocks = [b for b in range(rank, n_blocks, world)]
-    local = torch.zeros((per_rank * ROW_BLOCK, WIDTH, 3), dtype=torch.float32, device=dev)
+    # interleaved 16-row blocks, block b belongs to rank b % world (ray-tracer_amd/tiling.py)
+    my_blocks = tiling.blocks_of_rank(rank, world, HEIGHT)
+    local = tiling.local_buffer(world, WIDTH, HEIGHT, dev)
     gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
 
-    def render_frame(p, want_stats):
-        """Renders this rank's rows into `local` (block k of this rank at rows [k*16, k*16+16) of `local`)."""
+    def render_frame(p):
+        """Renders this rank's rows into `local`; returns the summed rt_stats of its rt_render calls."""
         total = rt.Stats()
-        if world == 1:
-            _, st = lib.render(bvh, cam, lights, n_lights, feats, p, WIDTH, HEIGHT, 0, HEIGHT, out=local.data_ptr(), device_ptr=1, stream=stream)
-            return st
-        for k, b in enumerate(my_blocks):
-            # block b covers Screen rows [b*16, ...): bottom-up rows [H - end, H - begin)
-            top, bot = b * ROW_BLOCK, min(HEIGHT, (b + 1) * ROW_BLOCK)
-            _, st = lib.render(bvh, cam, lights, n_lights, feats, p, WIDTH, HEIGHT, HEIGHT - bot, HEIGHT - top,
-                               out=local.data_ptr() + k * ROW_BLOCK * WIDTH * 12, device_ptr=1, stream=stream)
+
+        def render_rows(row_begin, row_end, out):
+            _, st = lib.render(bvh, cam, lights, n_lights, feats, p, WIDTH, HEIGHT, row_begin, row_end, out=out.data_ptr(), device_ptr=1, stream=stream)
             for name, _ in rt.Stats._fields_:
                 setattr(total, name, getattr(total, name) + getattr(st, name))
+
+        if world == 1:
+            render_rows(0, HEIGHT, local)
+        else:
+            tiling.render_local(render_rows, rank, world, WIDTH, HEIGHT, local)
         return total
 
     def step():
-        st = render_frame(params, True)
+        st = render_frame(params)
         if world > 1:
-            dist.gather(local, gathered, dst=0)
+            tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered)
         return st
 
     def barrier():
@@ -140,9 +138,9 @@ def main():
 
     # one untimed frame with test counting on, for the roofline numerator (counts are deterministic)
     count_params = rt.default_params(ray_multiplier=4, count_tests=1)
-    cst = render_frame(count_params, True)
+    cst = render_frame(count_params)
     torch.cuda.synchronize()
-    my_pixels = WIDTH * sum(min(HEIGHT, (b + 1) * ROW_BLOCK) - b * ROW_BLOCK for b in my_blocks)
+    my_pixels = WIDTH * sum(tiling.block_rows(b, HEIGHT)[1] - tiling.block_rows(b, HEIGHT)[0] for b in my_blocks)
     launch_bytes = algorithmic_bytes(cst, my_pixels)
     launch_flops = algorithmic_flops(cst)
     avg_kernel_s = kernel_ms / args.steps / 1e3
@@ -168,17 +166,17 @@ def main():
                 "triangles": scene.n_triangles,
                 "bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)),
                 "rays_per_frame": rays // args.steps,
-                "partition": "whole frame" if world == 1 else f"interleaved {ROW_BLOCK}-row blocks over {world} ranks, gather to rank 0",
+                "partition": "whole frame" if world == 1 else f"interleaved {tiling.ROW_BLOCK}-row blocks over {world} ranks, gather to rank 0",
             },
             "frame_ms": frame_ms,
             "roofline": {
-                "kernel": "k_render",
+                "kernel": "k_primary + k_shadow + k_shade (the traversal/shading launches of one rt_render call)",
                 "bound": "hbm",
                 "achieved": launch_bytes / avg_kernel_s / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": launch_bytes / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(world),
                 "kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_launch": launch_bytes,
                 "valu": {"achieved": launch_flops / avg_kernel_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -193,6 +191,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(world):
+    """HBM bytes per frame from the committed rocprofv3 PMC passes of this same command (profiles/<tag>/traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as the gfx950 note prescribes), or None when
+    no measurement of the current kernels is committed."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_frame")
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(rt, scene, cam, feats, params):

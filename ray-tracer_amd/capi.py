@@ -267,6 +267,33 @@ class SceneData:
         else:
             self.desc.skybox = None
 
+    def write_binary(self, path):
+        """Writes the flat scene file the C++ facade's loadSceneBinary reads (magic RTSCENE1)."""
+        import struct
+
+        def image(f, img):
+            f.write(struct.pack("<ii", img.shape[1], img.shape[0]))
+            raw = img.tobytes()
+            f.write(raw + b"\0" * (-len(raw) % 4))
+
+        with open(path, "wb") as f:
+            f.write(b"RTSCENE1")
+            f.write(struct.pack("<8I", len(self.meshes), len(self.textures), self.spheres.shape[0], self.lights.shape[0],
+                                1 if self.skybox is not None else 0, 0, 0, 0))
+            for m in self.meshes:
+                f.write(struct.pack("<II", m["vertices"].shape[0], m["triangles"].shape[0]))
+                f.write(struct.pack("<8f", *[float(v) for v in m["kd"]], *[float(v) for v in m["ks"]], float(m["shininess"]), float(m["transparency"])))
+                f.write(struct.pack("<i", int(m.get("texture", -1))))
+                f.write(m["vertices"].tobytes())
+                f.write(m["triangles"].tobytes())
+            for t in self.textures:
+                image(f, t)
+            f.write(self.spheres.tobytes())
+            f.write(self.lights.tobytes())
+            if self.skybox is not None:
+                for face in self.skybox:
+                    image(f, face)
+
     def light_array(self, lights=None):
         src = self.lights if lights is None else np.asarray(lights, dtype=np.float32).reshape(-1, 22)
         arr = (Light * max(len(src), 1))()

@@ -1,0 +1,56 @@
+// Small driver over the C++ facade, used by the tests: loads a binary scene, renders one frame through
+// BvhInterface + renderRayTracing exactly the way the reference's CLI mode does (src/main.cpp:523-545), and
+// writes the float frame (and optionally a BMP).
+//   facade_render <scene.rtscene> <out.f32> <width> <height> <feature flags, comma separated> [out.bmp]
+#include "rt_facade.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+using namespace rtamd;
+
+int main(int argc, char** argv)
+{
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: facade_render scene out.f32 W H flags [out.bmp]\n");
+        return 2;
+    }
+    Scene scene = loadSceneBinary(argv[1]);
+    const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);
+    Features f;
+    f.enableAccelStructure = true;
+    std::string flags = argv[5];
+    auto has = [&](const char* name) { return ("," + flags + ",").find(std::string(",") + name + ",") != std::string::npos; };
+    f.enableShading = has("shading");
+    f.enableRecursive = has("recursive");
+    f.enableHardShadow = has("hard");
+    f.enableSoftShadow = has("soft");
+    f.enableNormalInterp = has("normals");
+    f.enableTextureMapping = has("textures");
+    f.extra.enableBloomEffect = has("bloom");
+    f.extra.enableTransparency = has("transparency");
+    f.extra.enableMultipleRaysPerPixel = has("multi2");
+    if (has("multi2")) rayMultiplier = 2;
+    BvhInterface bvh(&scene, f);
+    std::printf("levels %d leaves %d\n", bvh.numLevels(), bvh.numLeaves());
+    Screen screen({ W, H });
+    // the reference's default camera, src/config.h:16-21 (degrees converted like glm::radians)
+    const float rad = 0.01745329251994329576923690768489f;
+    Trackball camera(float(W) / float(H), 50.0f * rad, vec3(0.0f), 3.0f);
+    camera.setCamera(vec3(0.0f), vec3(20.0f * rad, 20.0f * rad, 0.0f), 3.0f);
+    renderRayTracing(scene, camera, bvh, screen, f);
+    // one debug ray through the pixel in the middle, like the GUI's ray inspector (src/main.cpp:155-158)
+    Ray ray = camera.generateRay({ 0.0f, 0.0f });
+    HitInfo hit;
+    const bool ok = bvh.intersect(ray, hit, f);
+    std::printf("centre ray hit %d t %.9g\n", int(ok), double(ray.t));
+    std::ofstream out(argv[2], std::ios::binary);
+    out.write(reinterpret_cast<const char*>(screen.pixels().data()), std::streamsize(screen.pixels().size() * sizeof(vec3)));
+    if (argc > 6) screen.writeBitmapToFile(argv[6]);
+    const rt_stats& st = lastRenderStats();
+    std::printf("rays %llu kernel_ms %.3f\n", (unsigned long long)(st.primary_rays + st.shadow_rays + st.bounce_rays), double(st.kernel_ms));
+    return 0;
+}

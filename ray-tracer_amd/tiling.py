@@ -1,0 +1,68 @@
+"""Row tiling of a frame across ranks (one process per GPU) and the gather of the tiles on rank 0.
+
+The reference parallelises over image rows with OpenMP (reference src/render.cpp:86-89); across GPUs the
+same independence is used: the scene is replicated, the frame is cut into blocks of ROW_BLOCK consecutive
+Screen rows, block b belongs to rank b % world (interleaved, so every rank gets a share of the busy middle of
+the picture), and the only exchange is one gather of the rendered blocks to rank 0.  Random streams are keyed
+by absolute pixel, so the assembled frame does not depend on the number of ranks.
+"""
+import torch
+import torch.distributed as dist
+
+ROW_BLOCK = 16
+
+
+def num_blocks(height, block=ROW_BLOCK):
+    return (height + block - 1) // block
+
+
+def blocks_of_rank(rank, world, height, block=ROW_BLOCK):
+    return list(range(rank, num_blocks(height, block), world))
+
+
+def blocks_per_rank(world, height, block=ROW_BLOCK):
+    return (num_blocks(height, block) + world - 1) // world
+
+
+def block_rows(b, height, block=ROW_BLOCK):
+    """Block b as (screen_top, screen_bottom, row_begin, row_end): Screen rows [top, bottom) counted from the
+    top of the picture, and the same rows counted from the bottom, which is what rt_render takes."""
+    top, bottom = b * block, min(height, (b + 1) * block)
+    return top, bottom, height - bottom, height - top
+
+
+def local_buffer(world, width, height, device, block=ROW_BLOCK):
+    """Per-rank tile store: blocks_per_rank slots of `block` rows each (the last block may be short)."""
+    return torch.zeros((blocks_per_rank(world, height, block) * block, width, 3), dtype=torch.float32, device=device)
+
+
+def render_local(render_rows, rank, world, width, height, local, block=ROW_BLOCK):
+    """Calls render_rows(row_begin, row_end, out) for every block of this rank; `out` is the [rows, width, 3]
+    view of `local` the block's pixels go to (top-most row first)."""
+    results = []
+    for k, b in enumerate(blocks_of_rank(rank, world, height, block)):
+        top, bottom, row_begin, row_end = block_rows(b, height, block)
+        results.append(render_rows(row_begin, row_end, local[k * block:k * block + (bottom - top)]))
+    return results
+
+
+def gather_frame(local, rank, world, width, height, block=ROW_BLOCK, gathered=None):
+    """Gathers every rank's tile store on rank 0 and returns the assembled [height, width, 3] frame there
+    (None elsewhere).  `gathered` may carry preallocated receive buffers across frames."""
+    if world == 1:
+        return local[:height]
+    if rank == 0 and gathered is None:
+        gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.gather(local, gathered if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    return assemble(gathered, world, width, height, block)
+
+
+def assemble(gathered, world, width, height, block=ROW_BLOCK):
+    frame = torch.empty((height, width, 3), dtype=gathered[0].dtype, device=gathered[0].device)
+    for r in range(world):
+        for k, b in enumerate(blocks_of_rank(r, world, height, block)):
+            top, bottom, _, _ = block_rows(b, height, block)
+            frame[top:bottom] = gathered[r][k * block:k * block + (bottom - top)]
+    return frame

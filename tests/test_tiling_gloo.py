@@ -1,0 +1,76 @@
+"""Multi-process (gloo, CPU) test of the row tiling + gather used for N > 1 GPUs.  The rows are rendered by
+the oracle here; on GPUs the same tiling code drives rt_render (bench.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as o
+
+rt = o.rt
+tiling = __import__("importlib").import_module("ray-tracer_amd.tiling")
+
+W, H = 40, 52  # 4 blocks of 16 rows, the last one short
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = o.golden("cornell_para")
+    sc = rt.SceneData.from_golden(g)
+    orc = o.OracleScene(sc)
+    cam = rt.make_camera(width=W, height=H, **o.CAM_A)
+    feats = rt.features(shading=1, soft_shadow=1, multiple_rays=1)
+    params = rt.default_params(ray_multiplier=2)
+    local = tiling.local_buffer(world, W, H, "cpu")
+
+    def render_rows(row_begin, row_end, out):
+        img, stats = orc.render(cam, feats, params, W, H, row_begin=row_begin, row_end=row_end, threads=1)
+        out.copy_(torch.from_numpy(img))
+        return stats.total_rays()
+
+    rays = sum(tiling.render_local(render_rows, rank, world, W, H, local))
+    frame = tiling.gather_frame(local, rank, world, W, H)
+    total = torch.tensor([rays], dtype=torch.int64)
+    dist.all_reduce(total)
+    if rank == 0:
+        np.save(out_path, frame.numpy())
+        np.save(out_path + ".rays.npy", total.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tiles_gather_to_the_single_process_frame(tmp_path, world):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    frame = np.load(out)
+    g = o.golden("cornell_para")
+    orc = o.OracleScene(rt.SceneData.from_golden(g))
+    ref, stats = orc.render(rt.make_camera(width=W, height=H, **o.CAM_A), rt.features(shading=1, soft_shadow=1, multiple_rays=1),
+                            rt.default_params(ray_multiplier=2), W, H, threads=1)
+    assert np.array_equal(frame, ref)  # independent of the number of ranks, bit for bit
+    assert int(np.load(out + ".rays.npy")[0]) == stats.total_rays()
+
+
+def test_block_bookkeeping():
+    for world in (1, 2, 4, 8):
+        seen = []
+        for r in range(world):
+            seen += tiling.blocks_of_rank(r, world, 1080)
+        assert sorted(seen) == list(range(tiling.num_blocks(1080)))
+    top, bottom, rb, re_ = tiling.block_rows(67, 1080)
+    assert (top, bottom, rb, re_) == (1072, 1080, 0, 8)
