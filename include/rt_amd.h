@@ -163,6 +163,10 @@ typedef struct rt_stats {
     uint64_t transparency_overflows;
     float kernel_ms;  /* device time of this call's traversal/shading kernel launches (HIP events on the call's stream) */
     float resolve_ms; /* device time of the sample-resolve pass (0 when one sample per pixel) */
+    /* breakdown when the call ran as primary / shadow / shade passes in a single chunk (else zero): */
+    uint64_t shadow_box_tests, shadow_triangle_tests; /* part of box_tests / triangle_tests done by the shadow pass */
+    float primary_ms, shadow_ms, shade_ms;
+    float reserved;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device copy of geometry, materials, textures, skybox */

@@ -187,6 +187,12 @@ class Stats(C.Structure):
         ("transparency_overflows", C.c_uint64),
         ("kernel_ms", C.c_float),
         ("resolve_ms", C.c_float),
+        ("shadow_box_tests", C.c_uint64),
+        ("shadow_triangle_tests", C.c_uint64),
+        ("primary_ms", C.c_float),
+        ("shadow_ms", C.c_float),
+        ("shade_ms", C.c_float),
+        ("reserved", C.c_float),
     ]
 
     def total_rays(self):

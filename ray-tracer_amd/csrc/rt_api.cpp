@@ -89,7 +89,7 @@ struct rt_bvh {
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
     DevBuf stats, frame, queue, queueCounters, visibility, samples, dofFlags, rays, hits, misc, bloomWeights;
-    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr;
+    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[3] = { nullptr, nullptr, nullptr };
 };
 
 namespace {
@@ -248,6 +248,7 @@ rt_status upload_bvh(rt_bvh* b)
     RT_HIP(b->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
     RT_HIP(hipEventCreate(&b->evStart));
     RT_HIP(hipEventCreate(&b->evMid));
+    for (hipEvent_t& e : b->evSplit) RT_HIP(hipEventCreate(&e));
     RT_HIP(hipEventCreate(&b->evStop));
     SceneView& v = b->view;
     v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
@@ -362,6 +363,8 @@ void rt_bvh_destroy(rt_bvh* b)
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
+    for (hipEvent_t e : b->evSplit)
+        if (e) (void)hipEventDestroy(e);
     if (b->evStop) (void)hipEventDestroy(b->evStop);
     delete b;
 }
@@ -520,7 +523,8 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     // a synchronous wait is only needed when the caller wants numbers or host pixels back
     const bool wait = stats != nullptr || !devicePtr;
     if (stats) RT_HIP(hipEventRecord(b->evStart, s));
-    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr));
+    bool splitRecorded = false;
+    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr, stats ? b->evSplit : nullptr, &splitRecorded));
     if (stats) RT_HIP(hipEventRecord(b->evStop, s));
     if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
     if (wait) RT_HIP(hipStreamSynchronize(s));
@@ -536,6 +540,13 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         stats->transparency_overflows = h[STAT_OVERFLOW];
         RT_HIP(hipEventElapsedTime(&stats->kernel_ms, b->evStart, b->evMid));
         RT_HIP(hipEventElapsedTime(&stats->resolve_ms, b->evMid, b->evStop));
+        stats->shadow_box_tests = h[STAT_SHADOW_BOX];
+        stats->shadow_triangle_tests = h[STAT_SHADOW_TRI];
+        if (splitRecorded) {
+            RT_HIP(hipEventElapsedTime(&stats->primary_ms, b->evStart, b->evSplit[0]));
+            RT_HIP(hipEventElapsedTime(&stats->shadow_ms, b->evSplit[0], b->evSplit[1]));
+            RT_HIP(hipEventElapsedTime(&stats->shade_ms, b->evSplit[1], b->evSplit[2]));
+        }
     }
     return RT_OK;
 }

@@ -6,11 +6,13 @@
 
 namespace rt {
 
-enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_COUNT };
+enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_SHADOW_BOX, STAT_SHADOW_TRI, STAT_COUNT };
 
 // Renders rows [P.rowBegin, P.rowEnd): the traversal/shading passes, then (more than one sample per pixel)
-// the resolve pass.  `afterPasses`, when not null, is recorded between the two.
-hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses);
+// the resolve pass.  `afterPasses`, when not null, is recorded between the two.  `split`, when not null, points
+// to three events recorded after the primary, shadow and shade kernels if the call runs as those three passes
+// in a single chunk; *splitRecorded says whether that happened.
+hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded);
 
 // n closest-hit queries; rays/hits are device pointers.
 hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n, rt_hit* hits, hipStream_t stream);

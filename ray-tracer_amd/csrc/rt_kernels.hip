@@ -16,14 +16,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
-__device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* stats)
+__device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* stats, bool shadowPass = false)
 {
     if (!stats) return;
-    const uint32_t vals[STAT_COUNT] = { c.primary, c.shadow, c.bounce, c.probe, c.box, c.tri, c.overflow };
+    const uint32_t vals[7] = { c.primary, c.shadow, c.bounce, c.probe, c.box, c.tri, c.overflow };
 #pragma unroll
-    for (int i = 0; i < STAT_COUNT; i++) {
+    for (int i = 0; i < 7; i++) {
         const uint32_t s = wave_sum(vals[i]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&stats[i], (unsigned long long)s);
+        if ((threadIdx.x & 63) == 0 && s) {
+            atomicAdd(&stats[i], (unsigned long long)s);
+            if (shadowPass && i == STAT_BOX) atomicAdd(&stats[STAT_SHADOW_BOX], (unsigned long long)s);
+            if (shadowPass && i == STAT_TRI) atomicAdd(&stats[STAT_SHADOW_TRI], (unsigned long long)s);
+        }
     }
 }
 
@@ -264,7 +268,7 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
         }
         if (work < total) P.visibility[work] = (traced && blocked) ? 0 : 1;
     }
-    flush_counts(cnt, P.stats);
+    flush_counts(cnt, P.stats, true);
 }
 
 // Shade pass: one lane per queued hit — direct lighting with the visibility bits of the shadow pass
@@ -441,10 +445,11 @@ uint32_t resident_blocks(K kernel, int threads, size_t lds)
 }
 
 template <bool PRUNE>
-hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size_t lds, hipStream_t stream)
+hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev)
 {
     if (P.countTests) hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
     else hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
+    if (ev) (void)hipEventRecord(ev[0], stream);
     if (P.shadowSamplesPerHit > 0) {
         static const uint32_t residentCount = resident_blocks(k_shadow<true>, WAVE, 0);
         static const uint32_t resident = resident_blocks(k_shadow<false>, WAVE, 0);
@@ -453,7 +458,9 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
         if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), 0, stream, P);
         else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), 0, stream, P);
     }
+    if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+    if (ev) (void)hipEventRecord(ev[2], stream);
     return hipGetLastError();
 }
 
@@ -464,8 +471,9 @@ bool direct_only(const FrameParams& P)
     return !(P.f.recursive || P.f.glossy || P.f.transparency || P.f.depth_of_field || (P.f.environment_mapping && P.p.enabled_refl_map));
 }
 
-hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses)
+hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* splitEvents, bool* splitRecorded)
 {
+    if (splitRecorded) *splitRecorded = false;
     FrameParams P = Pin;
     const int rows = P.rowEnd - P.rowBegin;
     if (rows <= 0 || P.width <= 0) return hipSuccess;
@@ -483,7 +491,9 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
             if ((e = hipMemsetAsync(P.queueCounters, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
-            return prune ? launch_split_t<true>(P, grid, gridDirect, lds, stream) : launch_split_t<false>(P, grid, gridDirect, lds, stream);
+            hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
+            if (ev && splitRecorded) *splitRecorded = true;
+            return prune ? launch_split_t<true>(P, grid, gridDirect, lds, stream, ev) : launch_split_t<false>(P, grid, gridDirect, lds, stream, ev);
         }
         if (prune) return glossy ? launch_render_t<true, true>(P, grid, lds, stream) : launch_render_t<true, false>(P, grid, lds, stream);
         return glossy ? launch_render_t<false, true>(P, grid, lds, stream) : launch_render_t<false, false>(P, grid, lds, stream);
