@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -483,6 +484,13 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     fill_lights(lights, nLights, *features, *params, P.lights, P.drawsPerHit);
     P.nLights = nLights;
     P.shadowSamplesPerHit = number_shadow_samples(P.lights, nLights, *features);
+    {
+        static const int sparseBelow = [] {
+            const char* e = std::getenv("RT_SPARSE_BELOW"); // tuning knob; default chosen by measurement
+            return e ? std::atoi(e) : 16;
+        }();
+        P.sparseBelow = sparseBelow;
+    }
 
     int spp = 1;
     if (features->multiple_rays) spp = params->ray_multiplier * params->ray_multiplier;

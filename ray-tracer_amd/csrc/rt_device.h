@@ -54,6 +54,7 @@ struct FrameParams {
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
     int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features
+    int32_t sparseBelow;         // shadow packets: a node entered by fewer rays than this goes to per-ray stacks
 };
 
 struct Counts {

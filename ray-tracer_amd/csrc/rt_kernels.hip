@@ -166,14 +166,19 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
 // the cursor has passed the packet count.
 struct PacketEntry {
     int32_t ref;
-    uint32_t pad;
+    int32_t level; // tree level of `ref` (root = 0)
     unsigned long long mask;
 };
+
+constexpr int LANE_STACK_EXTRA = 12; // per-lane stack entries beyond the tree depth
 
 template <bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
 {
     __shared__ PacketEntry stack[RT_MAX_LEVELS + 1];
+    extern __shared__ int32_t laneStackBase[]; // [entry][lane]
+    int32_t* laneStack = laneStackBase + threadIdx.x;
+    const int laneCap = P.scene.stackDepth + LANE_STACK_EXTRA;
     const int lane = int(threadIdx.x);
     Counts cnt;
     const SceneView& S = P.scene;
@@ -218,13 +223,22 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
         unsigned long long alive = __ballot(traced); // rays still undecided
         unsigned long long mask = alive;             // rays inside `cur`
         int32_t cur = S.rootRef;
+        int level = 0;
         int sp = 0;
+        int mine_n = 0; // entries on this lane's own stack
+        // ---- dense phase: the wave walks the nodes many of its rays are in, together
         while (alive) {
             const unsigned long long in = mask & alive;
             bool descend = false;
             if (in) {
                 const bool mine = (in >> lane) & 1ull;
-                if (cur >= 0) {
+                // A node only a few rays are in is cheaper to finish by those rays on their own (next phase),
+                // provided each of them has room for it plus the subtree below it on its stack.
+                bool sparse = int(__popcll(in)) < P.sparseBelow;
+                if (sparse) sparse = !__ballot(mine && mine_n + (P.scene.stackDepth - level) + 1 > laneCap);
+                if (sparse) {
+                    if (mine) laneStack[(mine_n++) * WAVE] = cur;
+                } else if (cur >= 0) {
                     const Rec64 nd = load_rec_uniform(&S.nodes[__builtin_amdgcn_readfirstlane(cur)]);
                     float tL, tR;
                     if (COUNT && mine) cnt.box += 2;
@@ -235,8 +249,10 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
                     if (mL | mR) {
                         // visit the child more rays are in first; park the other one
                         const bool leftFirst = mR == 0 || (mL != 0 && __popcll(mL) >= __popcll(mR));
+                        level++;
                         if (mL && mR) {
                             stack[sp].ref = leftFirst ? refR : refL; // same value from every lane
+                            stack[sp].level = level;
                             stack[sp].mask = leftFirst ? mR : mL;
                             sp++;
                         }
@@ -263,7 +279,49 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
                 if (sp == 0) break;
                 --sp;
                 cur = stack[sp].ref;
+                level = stack[sp].level;
                 mask = stack[sp].mask;
+            }
+        }
+        // ---- sparse phase: every ray finishes the nodes handed to it with a traversal of its own; the rays of
+        //      the wave are now in different nodes and work on them in parallel
+        {
+            constexpr int32_t DONE = INT32_MIN;
+            int32_t c = DONE;
+            if (!blocked && mine_n > 0) c = laneStack[(--mine_n) * WAVE];
+            while (__ballot(c != DONE)) {
+                while (c >= 0) {
+                    const Rec64 nd = load_rec(&S.nodes[c]);
+                    float tL, tR;
+                    if (COUNT) cnt.box += 2;
+                    const bool vL = box_entry_left(r, nd, tL) && tL < FLT_MAX;
+                    const bool vR = box_entry_right(r, nd, tR) && tR < FLT_MAX;
+                    const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
+                    if (vL && vR) {
+                        laneStack[(mine_n++) * WAVE] = refR;
+                        c = refL;
+                    } else if (vL || vR) {
+                        c = vL ? refL : refR;
+                    } else {
+                        c = mine_n > 0 ? laneStack[(--mine_n) * WAVE] : DONE;
+                    }
+                }
+                if (c != DONE) {
+                    int32_t slot = ~c;
+                    int32_t more;
+                    do {
+                        const Rec64 p = load_rec(&S.prims[slot]);
+                        more = prim_more(p);
+                        if (COUNT) cnt.tri++;
+                        float t;
+                        if (triangle_hit(r, p, 1.0f, t)) {
+                            blocked = true;
+                            break;
+                        }
+                        slot++;
+                    } while (more > 0);
+                    c = (!blocked && mine_n > 0) ? laneStack[(--mine_n) * WAVE] : DONE;
+                }
             }
         }
         if (work < total) P.visibility[work] = (traced && blocked) ? 0 : 1;
@@ -451,12 +509,11 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
     else hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (P.shadowSamplesPerHit > 0) {
-        static const uint32_t residentCount = resident_blocks(k_shadow<true>, WAVE, 0);
-        static const uint32_t resident = resident_blocks(k_shadow<false>, WAVE, 0);
-        const uint32_t cap = P.countTests ? residentCount : resident;
+        const size_t laneLds = size_t(WAVE) * size_t(P.scene.stackDepth + LANE_STACK_EXTRA) * sizeof(int32_t);
+        const uint32_t cap = P.countTests ? resident_blocks(k_shadow<true>, WAVE, laneLds) : resident_blocks(k_shadow<false>, WAVE, laneLds);
         const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
-        if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), 0, stream, P);
-        else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), 0, stream, P);
+        if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), laneLds, stream, P);
+        else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), laneLds, stream, P);
     }
     if (ev) (void)hipEventRecord(ev[1], stream);
     hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
