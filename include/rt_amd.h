@@ -166,7 +166,11 @@ typedef struct rt_stats {
     /* breakdown when the call ran as primary / shadow / shade passes in a single chunk (else zero): */
     uint64_t shadow_box_tests, shadow_triangle_tests; /* part of box_tests / triangle_tests done by the shadow pass */
     float primary_ms, shadow_ms, shade_ms;
-    float reserved;
+    float cull_ms;
+    /* shadow queries the reference would trace whose outcome cannot reach the pixel (the Phong term of that light
+     * sample is exactly zero because the surface faces away from it) and that the library therefore does not trace;
+     * shadow_rays counts traced queries only */
+    uint64_t culled_shadow_rays;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device copy of geometry, materials, textures, skybox */

@@ -192,11 +192,17 @@ class Stats(C.Structure):
         ("primary_ms", C.c_float),
         ("shadow_ms", C.c_float),
         ("shade_ms", C.c_float),
-        ("reserved", C.c_float),
+        ("cull_ms", C.c_float),
+        ("culled_shadow_rays", C.c_uint64),
     ]
 
     def total_rays(self):
+        """Queries actually traced."""
         return self.primary_rays + self.shadow_rays + self.bounce_rays + self.probe_rays
+
+    def reference_rays(self):
+        """Queries the reference's algorithm issues for the same frame (traced + culled)."""
+        return self.total_rays() + self.culled_shadow_rays
 
 
 class SceneData:

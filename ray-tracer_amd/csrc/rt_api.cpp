@@ -89,8 +89,8 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, visibility, samples, dofFlags, rays, hits, misc, bloomWeights;
-    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[3] = { nullptr, nullptr, nullptr };
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, samples, dofFlags, rays, hits, misc, bloomWeights;
+    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
 };
 
 namespace {
@@ -360,7 +360,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -487,7 +487,7 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     {
         static const int sparseBelow = [] {
             const char* e = std::getenv("RT_SPARSE_BELOW"); // tuning knob; default chosen by measurement
-            return e ? std::atoi(e) : 16;
+            return e ? std::atoi(e) : 24;
         }();
         P.sparseBelow = sparseBelow;
     }
@@ -513,7 +513,11 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         const size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
         RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
         RT_HIP(b->queueCounters.reserve(64));
-        RT_HIP(b->visibility.reserve(cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1)));
+        const size_t items = cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1);
+        if (items >= (size_t(1) << 32)) return fail(RT_ERR_LIMIT, "too many shadow samples per pass (pixels x samples x light samples must stay below 2^32)");
+        RT_HIP(b->visibility.reserve(items));
+        RT_HIP(b->shadowQueue.reserve(items * sizeof(uint32_t)));
+        P.shadowQueue = static_cast<uint32_t*>(b->shadowQueue.ptr);
         P.queue = static_cast<HitEntry*>(b->queue.ptr);
         P.queueCounters = static_cast<unsigned long long*>(b->queueCounters.ptr);
         P.visibility = static_cast<uint8_t*>(b->visibility.ptr);
@@ -550,10 +554,12 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         RT_HIP(hipEventElapsedTime(&stats->resolve_ms, b->evMid, b->evStop));
         stats->shadow_box_tests = h[STAT_SHADOW_BOX];
         stats->shadow_triangle_tests = h[STAT_SHADOW_TRI];
+        stats->culled_shadow_rays = h[STAT_CULLED];
         if (splitRecorded) {
             RT_HIP(hipEventElapsedTime(&stats->primary_ms, b->evStart, b->evSplit[0]));
-            RT_HIP(hipEventElapsedTime(&stats->shadow_ms, b->evSplit[0], b->evSplit[1]));
-            RT_HIP(hipEventElapsedTime(&stats->shade_ms, b->evSplit[1], b->evSplit[2]));
+            RT_HIP(hipEventElapsedTime(&stats->cull_ms, b->evSplit[0], b->evSplit[1]));
+            RT_HIP(hipEventElapsedTime(&stats->shadow_ms, b->evSplit[1], b->evSplit[2]));
+            RT_HIP(hipEventElapsedTime(&stats->shade_ms, b->evSplit[2], b->evSplit[3]));
         }
     }
     return RT_OK;

@@ -146,10 +146,91 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
     r = make_ray(o, d);
 }
 
+// Cull pass: one lane per queued hit.  Decides, for every shadow-casting light sample of the hit, whether the
+// visibility bit can reach the pixel at all.  With shading on, the reference multiplies the bit with a Phong
+// term (src/light.cpp:141-143,175-178,209-212) that is exactly zero when dot(N, L) <= 0 (src/shading.cpp:14-38):
+// diffuse and specular both vanish, so `shade * lighted` adds zero whatever the shadow ray would have found.
+// Those samples get visibility 1 without a ray; the others are appended to the shadow work queue, the items
+// of a hit next to each other and hits in queue order (one atomic per wave).
+__global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
+{
+    const unsigned int nHits = (unsigned int)P.queueCounters[0];
+    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
+    const int lane = int(threadIdx.x) & 63;
+    const unsigned int rounded = (nHits + 63u) & ~63u; // whole waves stay in the loop together
+    uint32_t culled = 0;
+    for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < rounded; q += gridDim.x * BLOCK) {
+        const bool live = q < nHits;
+        Rng rng;
+        RayD r = make_ray(splat3(0.0f), splat3(1.0f));
+        Surface s;
+        s.normal = splat3(0.0f);
+        float t = 0.0f;
+        if (live) {
+            const HitEntry e = P.queue[q];
+            size_t pix;
+            int sidx;
+            hit_ray(P, e, nPix, rng, r, pix, sidx);
+            s = surface_at(P, r, e.t, e.slot);
+            t = e.t;
+        }
+        const vec3 point = r.o + (r.d * t);
+        const vec3 N = normalize(s.normal);
+        uint32_t need = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            // pass 0 counts this hit's shadow rays, pass 1 writes them at the offset the wave reserved
+            uint32_t at = 0;
+            if (pass == 1) {
+                uint32_t prefix = need; // inclusive scan over the wave
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_up(prefix, off, 64);
+                    if (lane >= off) prefix += v;
+                }
+                const uint32_t total = __shfl(prefix, 63, 64);
+                unsigned long long base = 0;
+                if (lane == 63 && total) base = atomicAdd(&P.queueCounters[2], (unsigned long long)total);
+                base = __shfl(base, 63, 64);
+                at = uint32_t(base) + prefix - need;
+            }
+            if (live) {
+                for (int li = 0; li < P.nLights; li++) {
+                    const LightDev& L = P.lights[li];
+                    if (L.shadowBase < 0) continue;
+                    const int total = L.nA * L.nB;
+                    const uint32_t per = light_draws_per_sample(L.type);
+                    for (int k = 0; k < total; k++) {
+                        bool wanted = true;
+                        if (P.f.shading) {
+                            vec3 position, color;
+                            light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
+                            wanted = dot(N, normalize(position - point)) > 0; // same expression as phong()
+                        }
+                        const uint32_t item = q * perHit + uint32_t(L.shadowBase + k);
+                        if (pass == 0) {
+                            need += wanted ? 1u : 0u;
+                            if (!wanted) {
+                                P.visibility[item] = 1;
+                                culled++;
+                            }
+                        } else if (wanted) {
+                            P.shadowQueue[at++] = item;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (P.stats) {
+        const uint32_t c = wave_sum(culled);
+        if (lane == 0 && c) atomicAdd(&P.stats[STAT_CULLED], (unsigned long long)c);
+    }
+}
+
 // Shadow pass: one any-hit query per (queued hit, shadow-casting light sample) — testVisibilityLightSample,
 // reference src/light.cpp:68-89 — traced as wave-wide PACKETS of 64 rays.
 //
-// Work item w = hit * samplesPerHit + j; packet p holds items 64p .. 64p+63: the shadow rays of a few
+// Work item w = hit * samplesPerHit + j; packet p holds queued items 64p .. 64p+63 (see k_cull): the shadow rays of a few
 // neighbouring hit points towards one area light (or of an 8x8 pixel tile towards a point light), i.e.
 // nearly identical rays.  The whole wave walks the hierarchy together: ONE stack, ONE current node, whose
 // record is fetched with scalar loads (it is the same address for all lanes) and whose two boxes every lane
@@ -182,19 +263,22 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
     const int lane = int(threadIdx.x);
     Counts cnt;
     const SceneView& S = P.scene;
-    const unsigned long long perHit = (unsigned long long)P.shadowSamplesPerHit;
-    const unsigned long long total = P.queueCounters[0] * perHit;
-    const unsigned long long nPackets = (total + 63ull) / 64ull;
+    const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
+    const unsigned long long queued = P.queueCounters[2];
+    const unsigned long long nPackets = (queued + 63ull) / 64ull;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     while (true) {
         unsigned long long pk = 0;
         if (lane == 0) pk = atomicAdd(&P.queueCounters[1], 1ull);
         pk = __shfl(pk, 0, 64);
         if (pk >= nPackets) break;
-        const unsigned long long work = pk * 64ull + (unsigned long long)lane;
+        const unsigned long long qi = pk * 64ull + (unsigned long long)lane;
+        const bool have = qi < queued;
+        uint32_t work = 0;
         RayD r = make_ray(splat3(0.0f), splat3(1.0f));
         bool traced = false;
-        if (work < total) {
+        if (have) {
+            work = P.shadowQueue[qi];
             const HitEntry e = P.queue[work / perHit];
             const int j = int(work % perHit);
             Rng rng;
@@ -324,7 +408,7 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
                 }
             }
         }
-        if (work < total) P.visibility[work] = (traced && blocked) ? 0 : 1;
+        if (have) P.visibility[work] = (traced && blocked) ? 0 : 1;
     }
     flush_counts(cnt, P.stats, true);
 }
@@ -508,6 +592,8 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
     if (P.countTests) hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
     else hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
     if (ev) (void)hipEventRecord(ev[0], stream);
+    if (P.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+    if (ev) (void)hipEventRecord(ev[1], stream);
     if (P.shadowSamplesPerHit > 0) {
         const size_t laneLds = size_t(WAVE) * size_t(P.scene.stackDepth + LANE_STACK_EXTRA) * sizeof(int32_t);
         const uint32_t cap = P.countTests ? resident_blocks(k_shadow<true>, WAVE, laneLds) : resident_blocks(k_shadow<false>, WAVE, laneLds);
@@ -515,9 +601,9 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
         if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), laneLds, stream, P);
         else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), laneLds, stream, P);
     }
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     if (ev) (void)hipEventRecord(ev[2], stream);
+    hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+    if (ev) (void)hipEventRecord(ev[3], stream);
     return hipGetLastError();
 }
 
@@ -545,7 +631,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
         P.sampleEnd = sEnd;
         const dim3 grid(tiles * uint32_t(sEnd - sBegin));
         if (split) {
-            if ((e = hipMemsetAsync(P.queueCounters, 0, 2 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(P.queueCounters, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
