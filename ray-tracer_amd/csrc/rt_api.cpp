@@ -89,7 +89,7 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, samples, dofFlags, rays, hits, misc, bloomWeights;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, bloomWeights;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
 };
 
@@ -360,7 +360,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -485,11 +485,12 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     P.nLights = nLights;
     P.shadowSamplesPerHit = number_shadow_samples(P.lights, nLights, *features);
     {
-        static const int sparseBelow = [] {
-            const char* e = std::getenv("RT_SPARSE_BELOW"); // tuning knob; default chosen by measurement
-            return e ? std::atoi(e) : 24;
+        static const int pairStackLds = [] {
+            const char* e = std::getenv("RT_PAIR_STACK_LDS"); // tuning / test knob; default chosen by measurement
+            const int v = e ? std::atoi(e) : 512;
+            return v < 64 ? 64 : v;
         }();
-        P.sparseBelow = sparseBelow;
+        P.pairStackLds = pairStackLds;
     }
 
     int spp = 1;
@@ -518,6 +519,11 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         RT_HIP(b->visibility.reserve(items));
         RT_HIP(b->shadowQueue.reserve(items * sizeof(uint32_t)));
         P.shadowQueue = static_cast<uint32_t*>(b->shadowQueue.ptr);
+        rt::size_pair_stack(P);
+        if (P.pairSpillEntries > 0) {
+            RT_HIP(b->pairSpill.reserve(size_t(P.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
+            P.pairSpill = static_cast<uint32_t*>(b->pairSpill.ptr);
+        }
         P.queue = static_cast<HitEntry*>(b->queue.ptr);
         P.queueCounters = static_cast<unsigned long long*>(b->queueCounters.ptr);
         P.visibility = static_cast<uint8_t*>(b->visibility.ptr);

@@ -14,6 +14,10 @@ enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TR
 // in a single chunk; *splitRecorded says whether that happened.
 hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded);
 
+// Shadow pass sizing: clamps P.pairStackLds to what the hierarchy can need and sets P.pairSpillEntries (per wave)
+// and P.pairSpillWaves (the most waves the pass is launched with); the caller provides P.pairSpill accordingly.
+void size_pair_stack(FrameParams& P);
+
 // n closest-hit queries; rays/hits are device pointers.
 hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n, rt_hit* hits, hipStream_t stream);
 

@@ -227,188 +227,311 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     }
 }
 
-// Shadow pass: one any-hit query per (queued hit, shadow-casting light sample) — testVisibilityLightSample,
-// reference src/light.cpp:68-89 — traced as wave-wide PACKETS of 64 rays.
+// Shadow pass: one any-hit query per queued (hit, light sample) — testVisibilityLightSample, reference
+// src/light.cpp:68-89 — traced by a wave as a STREAM OF (ray, node) PAIRS.
 //
-// Work item w = hit * samplesPerHit + j; packet p holds queued items 64p .. 64p+63 (see k_cull): the shadow rays of a few
-// neighbouring hit points towards one area light (or of an 8x8 pixel tile towards a point light), i.e.
-// nearly identical rays.  The whole wave walks the hierarchy together: ONE stack, ONE current node, whose
-// record is fetched with scalar loads (it is the same address for all lanes) and whose two boxes every lane
-// tests against its own ray.  Control flow is wave-uniform; only the per-lane "is my ray in this node" bit
-// varies.
+// The answer of an any-hit query ("is any primitive accepted before the light") is the OR over the nodes the
+// ray enters, and entering a node depends only on the ray's own box tests on the way down.  So the pairs
+// (ray, node it has entered) of a packet of rays are independent pieces of work: any lane can take any pair,
+// test the node's two child boxes against that ray and emit up to two new pairs, in any order, and every ray
+// still performs exactly the box and primitive tests the reference's traversal makes for it before its first
+// accepted primitive.  The wave keeps the pairs of its packet on ONE stack in LDS and every step pops the top
+// 64: all lanes work as long as 64 pairs exist, however differently long the individual rays' traversals
+// are, and control flow is wave-uniform.  Pairs whose node is a leaf go to a second pool; a step that tests
+// primitives runs when 64 of those have gathered (or nothing else is left), so box tests and primitive tests
+// never share a step.  Rays live in LDS too (a lane works for a different ray every step); a ray that has
+// been blocked gets a flag in its record, and its remaining pairs are dropped when popped.
 //
-// This is exact, not an approximation: each stack entry carries the 64-bit set of rays that entered that
-// node through box tests of their own, a ray only tests the primitives of leaves it is in, and the answer of
-// an any-hit query ("is any primitive accepted before the light") does not depend on the order in which the
-// nodes a ray enters are visited.  So every ray performs exactly the box and primitive tests the reference's
-// traversal would make for it until its first accepted primitive, and gets the same boolean.
+// Stack bound.  Lane 0 pops the top entry, lane 1 the one below, and so on; the children are pushed in
+// reverse lane order (those of lane 63 lowest).  By induction the tree levels of the entries never decrease
+// from the bottom of the stack to the top: the popped entries are the deepest ones, their levels do not
+// increase with the lane index, and every child is deeper than everything left below.  Hence a step pops
+// level-l entries only together with ALL deeper entries, the level l+1 then consists of the new children
+// alone, and no level ever holds more than the 128 children of one step: 128 entries per inner level suffice.
 //
 // Persistent waves: a wave whose packet has ended takes the next one from a global cursor and stops once
 // the cursor has passed the packet count.
-struct PacketEntry {
-    int32_t ref;
-    int32_t level; // tree level of `ref` (root = 0)
-    unsigned long long mask;
+constexpr int STREAM_RAYS = 64;                           // rays per packet
+constexpr int STREAM_REF_BITS = 25;                       // pair = ray index (7 bits) | node index or primitive slot
+constexpr uint32_t STREAM_REF_MASK = (1u << STREAM_REF_BITS) - 1u;
+constexpr int STREAM_PER_LEVEL = 128;                     // stack entries per inner tree level
+constexpr int STREAM_LEAF_CAP = 192;                      // < 64 waiting + 128 from one step
+constexpr uint32_t RAY_BLOCKED = 8u, RAY_PRESENT = 16u;   // flag bits next to the three zero-direction bits
+
+constexpr int STREAM_STAGE_STRIDE = 1024 + 16;            // bytes between the four quarter-wave images of the record stage
+
+__host__ __device__ constexpr int stream_stack_entries(int levels) { return STREAM_PER_LEVEL * (levels < 2 ? 1 : levels - 1); }
+__host__ __device__ constexpr size_t stream_lds_bytes(int stackEntriesInLds)
+{
+    return size_t(STREAM_RAYS) * (64 + 4) + 4 * STREAM_STAGE_STRIDE + size_t(STREAM_LEAF_CAP) * 4 + size_t(stackEntriesInLds) * 4;
+}
+constexpr uint32_t STREAM_MAX_WAVES = 256u * 32u; // every wave slot of the chip
+
+// The pair stack of a wave: the first `ldsEntries` entries in LDS, the rest of the proven bound in a spill
+// area of the wave's own in device memory.  The spill is written and read by different lanes of the wave,
+// so it bypasses the per-CU cache (device-scope atomics); a wave rarely gets that deep.
+struct PairStack {
+    uint32_t* lds;
+    uint32_t* spill;
+    uint32_t ldsEntries;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const
+    {
+        if (i < ldsEntries) return lds[i];
+        return __hip_atomic_load(spill + (i - ldsEntries), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t v) const
+    {
+        if (i < ldsEntries) lds[i] = v;
+        else __hip_atomic_store(spill + (i - ldsEntries), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
-constexpr int LANE_STACK_EXTRA = 12; // per-lane stack entries beyond the tree depth
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// set bits of m in the lanes below / above this one
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+
+// One 64-byte record per lane (byte offset `off` from `base`, any valid offset for lanes that need nothing),
+// fetched so that a load instruction touches 16 cache lines instead of 64: the four lanes of a quad fetch the
+// four 16-byte quarters of ONE record per load (the record of quad lane 0, then 1, 2, 3).  The data go to the
+// LDS stage directly (destination = uniform base + lane * 16, which puts the quarters of a record next to each
+// other), from where every lane reads its own record back once stage_wait() has passed.  The images of the
+// four loads are 16 bytes apart modulo the bank width so that those reads do not collide.
+typedef __attribute__((address_space(3))) char* lds_bytes;
+__device__ __forceinline__ void stage_records(const void* base, uint32_t off, lds_bytes stage, uint32_t quarter)
+{
+    const char* g = static_cast<const char*>(base);
+    __builtin_amdgcn_global_load_lds(g + size_t(uint32_t(__builtin_amdgcn_update_dpp(0, int(off), 0x00, 0xf, 0xf, true)) + quarter), stage, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g + size_t(uint32_t(__builtin_amdgcn_update_dpp(0, int(off), 0x55, 0xf, 0xf, true)) + quarter), stage + STREAM_STAGE_STRIDE, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g + size_t(uint32_t(__builtin_amdgcn_update_dpp(0, int(off), 0xaa, 0xf, 0xf, true)) + quarter), stage + 2 * STREAM_STAGE_STRIDE, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(g + size_t(uint32_t(__builtin_amdgcn_update_dpp(0, int(off), 0xff, 0xf, 0xf, true)) + quarter), stage + 3 * STREAM_STAGE_STRIDE, 16, 0, 0);
+}
+__device__ __forceinline__ void stage_wait()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// LDS operations of a wave execute in order; this only keeps the compiler from moving them across (one wave per block)
+__device__ __forceinline__ void lds_fence()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+
+// "entered at all" of both child boxes of a node for a ray none of whose direction components is in the
+// zero class: box_entry() followed by the caller's `t < FLT_MAX`, with the twelve plane parameters computed
+// as packed pairs.  o01 = (ox, oy), o20 = (oz, ox), o12 = (oy, oz), likewise the reciprocals: the pairing of
+// the twelve consecutive floats lo.xyz hi.xyz lo.xyz hi.xyz of a node record.
+__device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, f32x2 o01, f32x2 o20, f32x2 o12, f32x2 i01, f32x2 i20, f32x2 i12, bool& left, bool& right)
+{
+    const f32x2 p0 = (a.xy - o01) * i01; // left  lo.x lo.y
+    const f32x2 p1 = (a.zw - o20) * i20; // left  lo.z hi.x
+    const f32x2 p2 = (b.xy - o12) * i12; // left  hi.y hi.z
+    const f32x2 p3 = (b.zw - o01) * i01; // right lo.x lo.y
+    const f32x2 p4 = (c.xy - o20) * i20; // right lo.z hi.x
+    const f32x2 p5 = (c.zw - o12) * i12; // right hi.y hi.z
+    const float tinL = fmaxf(fmaxf(fminf(p0.x, p1.y), fminf(p0.y, p2.x)), fminf(p1.x, p2.y));
+    const float toutL = fminf(fminf(fmaxf(p0.x, p1.y), fmaxf(p0.y, p2.x)), fmaxf(p1.x, p2.y));
+    const float tinR = fmaxf(fmaxf(fminf(p3.x, p4.y), fminf(p3.y, p5.x)), fminf(p4.x, p5.y));
+    const float toutR = fminf(fminf(fmaxf(p3.x, p4.y), fmaxf(p3.y, p5.x)), fmaxf(p4.x, p5.y));
+    left = !(tinL > toutL) && !(toutL <= 0) && !is_zero(tinL) && (tinL < 0 ? toutL : tinL) < FLT_MAX;
+    right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR) && (tinR < 0 ? toutR : tinR) < FLT_MAX;
+}
 
 template <bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
 {
-    __shared__ PacketEntry stack[RT_MAX_LEVELS + 1];
-    extern __shared__ int32_t laneStackBase[]; // [entry][lane]
-    int32_t* laneStack = laneStackBase + threadIdx.x;
-    const int laneCap = P.scene.stackDepth + LANE_STACK_EXTRA;
+    // per ray: (ox oy oz ox) (oy oz ix iy) (iz ix iy iz) (dx dy dz flags), i = 1/d
+    extern __shared__ f32x4 streamLds[];
+    f32x4* rays = streamLds;
+    char* stage = reinterpret_cast<char*>(rays + STREAM_RAYS * 4);
+    uint32_t* workOf = reinterpret_cast<uint32_t*>(stage + 4 * STREAM_STAGE_STRIDE);
+    uint32_t* leafPool = workOf + STREAM_RAYS;
+    const PairStack pool { leafPool + STREAM_LEAF_CAP, P.pairSpill + size_t(blockIdx.x) * P.pairSpillEntries, uint32_t(P.pairStackLds) };
     const int lane = int(threadIdx.x);
     Counts cnt;
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const unsigned long long queued = P.queueCounters[2];
-    const unsigned long long nPackets = (queued + 63ull) / 64ull;
+    const unsigned long long nPackets = (queued + STREAM_RAYS - 1) / STREAM_RAYS;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const lds_bytes stageLds = (lds_bytes)stage;
+    const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
+    const uint32_t quarter = uint32_t(lane & 3) * 16u;
     while (true) {
         unsigned long long pk = 0;
         if (lane == 0) pk = atomicAdd(&P.queueCounters[1], 1ull);
         pk = __shfl(pk, 0, 64);
         if (pk >= nPackets) break;
-        const unsigned long long qi = pk * 64ull + (unsigned long long)lane;
-        const bool have = qi < queued;
-        uint32_t work = 0;
-        RayD r = make_ray(splat3(0.0f), splat3(1.0f));
-        bool traced = false;
-        if (have) {
-            work = P.shadowQueue[qi];
-            const HitEntry e = P.queue[work / perHit];
-            const int j = int(work % perHit);
-            Rng rng;
-            RayD cam;
-            size_t pix;
-            int sidx;
-            hit_ray(P, e, nPix, rng, cam, pix, sidx);
-            // which light and which of its samples: the last light whose first shadow sample is <= j
-            int li = 0;
-            for (int i = 0; i < P.nLights; i++)
-                if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
-            const LightDev& L = P.lights[li];
-            const int k = j - L.shadowBase;
-            vec3 position, color;
-            light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
-            const float epsilon = 0.00001f;
-            const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
-            r = make_ray(origin, position - origin);
-            cnt.shadow++;
-            float tRoot;
-            if (COUNT) cnt.box++;
-            // root gate against the shadow ray's own bound t = 1 (…hierarchy.cpp:296-301)
-            traced = box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f;
+        // ---- the packet's rays; the ones that pass the root gate start as pairs (ray, root)
+        uint32_t count = 0, leafCount = 0;
+        bool zeroClass = false; // some ray of the packet has a direction component in the zero class
+        for (int h = 0; h < STREAM_RAYS / WAVE; h++) {
+            const uint32_t rid = uint32_t(h * WAVE + lane);
+            const unsigned long long qi = pk * STREAM_RAYS + rid;
+            const bool have = qi < queued;
+            uint32_t work = 0;
+            RayD r = make_ray(splat3(0.0f), splat3(1.0f));
+            bool traced = false;
+            if (have) {
+                work = P.shadowQueue[qi];
+                const HitEntry e = P.queue[work / perHit];
+                const int j = int(work % perHit);
+                Rng rng;
+                RayD cam;
+                size_t pix;
+                int sidx;
+                hit_ray(P, e, nPix, rng, cam, pix, sidx);
+                // which light and which of its samples: the last light whose first shadow sample is <= j
+                int li = 0;
+                for (int i = 0; i < P.nLights; i++)
+                    if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
+                const LightDev& L = P.lights[li];
+                const int k = j - L.shadowBase;
+                vec3 position, color;
+                light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                const float epsilon = 0.00001f;
+                const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
+                r = make_ray(origin, position - origin);
+                cnt.shadow++;
+                float tRoot;
+                if (COUNT) cnt.box++;
+                // root gate against the shadow ray's own bound t = 1 (…hierarchy.cpp:296-301)
+                traced = box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f;
+            }
+            const uint32_t flags = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u) | (have ? RAY_PRESENT : 0u);
+            zeroClass = zeroClass || __ballot(flags & 7u) != 0;
+            f32x4* rec = rays + rid * 4;
+            rec[0] = f32x4 { r.o.x, r.o.y, r.o.z, r.o.x };
+            rec[1] = f32x4 { r.o.y, r.o.z, r.inv.x, r.inv.y };
+            rec[2] = f32x4 { r.inv.z, r.inv.x, r.inv.y, r.inv.z };
+            rec[3] = f32x4 { r.d.x, r.d.y, r.d.z, __uint_as_float(flags) };
+            workOf[rid] = work;
+            const unsigned long long m = __ballot(traced);
+            if (S.rootRef >= 0) {
+                if (traced) pool.put(count + lanes_below(m), (rid << STREAM_REF_BITS) | uint32_t(S.rootRef));
+                count += uint32_t(__popcll(m));
+            } else {
+                if (traced) leafPool[leafCount + lanes_below(m)] = (rid << STREAM_REF_BITS) | uint32_t(~S.rootRef);
+                leafCount += uint32_t(__popcll(m));
+            }
         }
-        bool blocked = false;
-        unsigned long long alive = __ballot(traced); // rays still undecided
-        unsigned long long mask = alive;             // rays inside `cur`
-        int32_t cur = S.rootRef;
-        int level = 0;
-        int sp = 0;
-        int mine_n = 0; // entries on this lane's own stack
-        // ---- dense phase: the wave walks the nodes many of its rays are in, together
-        while (alive) {
-            const unsigned long long in = mask & alive;
-            bool descend = false;
-            if (in) {
-                const bool mine = (in >> lane) & 1ull;
-                // A node only a few rays are in is cheaper to finish by those rays on their own (next phase),
-                // provided each of them has room for it plus the subtree below it on its stack.
-                bool sparse = int(__popcll(in)) < P.sparseBelow;
-                if (sparse) sparse = !__ballot(mine && mine_n + (P.scene.stackDepth - level) + 1 > laneCap);
-                if (sparse) {
-                    if (mine) laneStack[(mine_n++) * WAVE] = cur;
-                } else if (cur >= 0) {
-                    const Rec64 nd = load_rec_uniform(&S.nodes[__builtin_amdgcn_readfirstlane(cur)]);
-                    float tL, tR;
-                    if (COUNT && mine) cnt.box += 2;
-                    const bool vL = mine && box_entry_left(r, nd, tL) && tL < FLT_MAX;
-                    const bool vR = mine && box_entry_right(r, nd, tR) && tR < FLT_MAX;
-                    const unsigned long long mL = __ballot(vL), mR = __ballot(vR);
-                    const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
-                    if (mL | mR) {
-                        // visit the child more rays are in first; park the other one
-                        const bool leftFirst = mR == 0 || (mL != 0 && __popcll(mL) >= __popcll(mR));
-                        level++;
-                        if (mL && mR) {
-                            stack[sp].ref = leftFirst ? refR : refL; // same value from every lane
-                            stack[sp].level = level;
-                            stack[sp].mask = leftFirst ? mR : mL;
-                            sp++;
-                        }
-                        cur = leftFirst ? refL : refR;
-                        mask = leftFirst ? mL : mR;
-                        descend = true;
-                    }
+        lds_fence();
+        // ---- the stream
+        while (count | leafCount) {
+            if (count && leafCount < 64u) {
+                // box step: the top 64 pairs
+                const uint32_t k = count < 64u ? count : 64u;
+                const bool got = uint32_t(lane) < k;
+                const bool inLds = count + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
+                uint32_t e = 0u;
+                if (inLds) {
+                    if (got) e = pool.lds[count - 1u - uint32_t(lane)];
                 } else {
-                    int32_t slot = __builtin_amdgcn_readfirstlane(~cur);
-                    int32_t more;
-                    do {
-                        const Rec64 p = load_rec_uniform(&S.prims[slot]);
-                        more = prim_more(p);
-                        const bool test = mine && !blocked;
-                        if (COUNT && test) cnt.tri++;
-                        float t;
-                        if (test && triangle_hit(r, p, 1.0f, t)) blocked = true;
-                        slot++;
-                    } while (more > 0);
-                    alive &= ~__ballot(blocked);
+                    if (got) e = pool.get(count - 1u - uint32_t(lane));
                 }
-            }
-            if (!descend) {
-                if (sp == 0) break;
-                --sp;
-                cur = stack[sp].ref;
-                level = stack[sp].level;
-                mask = stack[sp].mask;
-            }
-        }
-        // ---- sparse phase: every ray finishes the nodes handed to it with a traversal of its own; the rays of
-        //      the wave are now in different nodes and work on them in parallel
-        {
-            constexpr int32_t DONE = INT32_MIN;
-            int32_t c = DONE;
-            if (!blocked && mine_n > 0) c = laneStack[(--mine_n) * WAVE];
-            while (__ballot(c != DONE)) {
-                while (c >= 0) {
-                    const Rec64 nd = load_rec(&S.nodes[c]);
-                    float tL, tR;
+                count -= k;
+                stage_records(S.nodes, (e & STREAM_REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
+                const uint32_t rid = e >> STREAM_REF_BITS;
+                const f32x4* rec = rays + rid * 4;
+                const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                const uint32_t flags = __float_as_uint(rec[3].w);
+                bool vL = false, vR = false;
+                int32_t refL = 0, refR = 0;
+                stage_wait();
+                if (got && !(flags & RAY_BLOCKED)) {
+                    const f32x4 a = staged[0], b = staged[1], c = staged[2];
+                    const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
                     if (COUNT) cnt.box += 2;
-                    const bool vL = box_entry_left(r, nd, tL) && tL < FLT_MAX;
-                    const bool vR = box_entry_right(r, nd, tR) && tR < FLT_MAX;
-                    const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
-                    if (vL && vR) {
-                        laneStack[(mine_n++) * WAVE] = refR;
-                        c = refL;
-                    } else if (vL || vR) {
-                        c = vL ? refL : refR;
+                    if (!zeroClass) {
+                        boxes_entered(a, b, c, r0.xy, r0.zw, r1.xy, r1.zw, r2.xy, r2.zw, vL, vR);
                     } else {
-                        c = mine_n > 0 ? laneStack[(--mine_n) * WAVE] : DONE;
+                        RayD r;
+                        r.o = make3(r0.x, r0.y, r0.z);
+                        r.inv = make3(r1.z, r1.w, r2.x);
+                        r.zx = flags & 1u; r.zy = flags & 2u; r.zz = flags & 4u;
+                        float tL, tR;
+                        vL = box_entry(r, a.x, a.y, a.z, a.w, b.x, b.y, tL) && tL < FLT_MAX;
+                        vR = box_entry(r, b.z, b.w, c.x, c.y, c.z, c.w, tR) && tR < FLT_MAX;
                     }
+                    refL = __float_as_int(refs.x);
+                    refR = __float_as_int(refs.y);
                 }
-                if (c != DONE) {
-                    int32_t slot = ~c;
+                const uint32_t tag = rid << STREAM_REF_BITS;
+                // children that are inner nodes go back on the stack, those of higher lanes lower
+                const bool iL = vL && refL >= 0, iR = vR && refR >= 0;
+                const unsigned long long bL = __ballot(iL), bR = __ballot(iR);
+                const uint32_t nL = uint32_t(__popcll(bL)), nR = uint32_t(__popcll(bR));
+                const uint32_t at = count + (nL - lanes_below(bL) - (iL ? 1u : 0u)) + (nR - lanes_below(bR) - (iR ? 1u : 0u));
+                if (inLds) {
+                    if (iL) pool.lds[at] = tag | uint32_t(refL);
+                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | uint32_t(refR);
+                } else {
+                    if (iL) pool.put(at, tag | uint32_t(refL));
+                    if (iR) pool.put(at + (iL ? 1u : 0u), tag | uint32_t(refR));
+                }
+                count += nL + nR;
+                // children that are leaves: to the primitive pool
+                const bool lL = vL && refL < 0, lR = vR && refR < 0;
+                const unsigned long long bLL = __ballot(lL), bLR = __ballot(lR);
+                if (lL) leafPool[leafCount + lanes_below(bLL)] = tag | uint32_t(~refL);
+                leafCount += uint32_t(__popcll(bLL));
+                if (lR) leafPool[leafCount + lanes_below(bLR)] = tag | uint32_t(~refR);
+                leafCount += uint32_t(__popcll(bLR));
+            } else {
+                // primitive step: up to 64 (ray, leaf) pairs
+                const uint32_t k = leafCount < 64u ? leafCount : 64u;
+                const bool got = uint32_t(lane) < k;
+                const uint32_t e = got ? leafPool[leafCount - 1u - uint32_t(lane)] : 0u;
+                leafCount -= k;
+                stage_records(S.prims, (e & STREAM_REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
+                const uint32_t rid = e >> STREAM_REF_BITS;
+                f32x4* rec = rays + rid * 4;
+                const f32x4 r0 = rec[0], r3 = rec[3];
+                stage_wait();
+                if (got && !(__float_as_uint(r3.w) & RAY_BLOCKED)) {
+                    RayD r;
+                    r.o = make3(r0.x, r0.y, r0.z);
+                    r.d = make3(r3.x, r3.y, r3.z);
+                    int32_t slot = int32_t(e & STREAM_REF_MASK);
                     int32_t more;
+                    bool first = true;
                     do {
-                        const Rec64 p = load_rec(&S.prims[slot]);
+                        // the leaf's first record is staged; further ones (leaves cut off by the level limit) come one by one
+                        Rec64 p;
+                        if (first) {
+                            const f32x4 q0 = staged[0], q1 = staged[1], q2 = staged[2], q3 = staged[3];
+                            p.a = make_float4(q0.x, q0.y, q0.z, q0.w);
+                            p.b = make_float4(q1.x, q1.y, q1.z, q1.w);
+                            p.c = make_float4(q2.x, q2.y, q2.z, q2.w);
+                            p.d = make_float4(q3.x, q3.y, q3.z, q3.w);
+                            first = false;
+                        } else {
+                            p = load_rec(&S.prims[slot]);
+                        }
                         more = prim_more(p);
                         if (COUNT) cnt.tri++;
                         float t;
                         if (triangle_hit(r, p, 1.0f, t)) {
-                            blocked = true;
+                            atomicOr(reinterpret_cast<uint32_t*>(rec + 3) + 3, RAY_BLOCKED);
                             break;
                         }
                         slot++;
                     } while (more > 0);
-                    c = (!blocked && mine_n > 0) ? laneStack[(--mine_n) * WAVE] : DONE;
                 }
             }
+            __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
         }
-        if (have) P.visibility[work] = (traced && blocked) ? 0 : 1;
+        for (int h = 0; h < STREAM_RAYS / WAVE; h++) {
+            const uint32_t rid = uint32_t(h * WAVE + lane);
+            const uint32_t flags = __float_as_uint(rays[rid * 4 + 3].w);
+            if (flags & RAY_PRESENT) P.visibility[workOf[rid]] = (flags & RAY_BLOCKED) ? 0 : 1;
+        }
+        lds_fence();
     }
     flush_counts(cnt, P.stats, true);
 }
@@ -595,8 +718,9 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
     if (P.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (P.shadowSamplesPerHit > 0) {
-        const size_t laneLds = size_t(WAVE) * size_t(P.scene.stackDepth + LANE_STACK_EXTRA) * sizeof(int32_t);
-        const uint32_t cap = P.countTests ? resident_blocks(k_shadow<true>, WAVE, laneLds) : resident_blocks(k_shadow<false>, WAVE, laneLds);
+        const size_t laneLds = stream_lds_bytes(P.pairStackLds);
+        uint32_t cap = P.countTests ? resident_blocks(k_shadow<true>, WAVE, laneLds) : resident_blocks(k_shadow<false>, WAVE, laneLds);
+        if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
         const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
         if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), laneLds, stream, P);
         else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), laneLds, stream, P);
@@ -608,6 +732,16 @@ hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size
 }
 
 } // namespace
+
+void size_pair_stack(FrameParams& P)
+{
+    const int bound = stream_stack_entries(P.scene.stackDepth);
+    if (P.pairStackLds > bound) P.pairStackLds = bound;
+    if (P.pairStackLds < 64) P.pairStackLds = bound < 64 ? bound : 64;
+    P.pairSpillEntries = uint32_t(bound - P.pairStackLds);
+    P.pairSpillWaves = STREAM_MAX_WAVES;
+    P.pairSpill = nullptr;
+}
 
 bool direct_only(const FrameParams& P)
 {
@@ -624,7 +758,9 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     const size_t lds = stack_bytes(P, WAVE);
     const bool prune = !P.f.recursive && !P.f.transparency;
     const bool glossy = P.f.glossy != 0;
-    const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P);
+    // the shadow pass packs a node index or primitive slot into STREAM_REF_BITS bits (inner nodes are fewer than primitives)
+    const bool fits = uint32_t(P.scene.numPrims) <= STREAM_REF_MASK && P.scene.stackDepth < 64;
+    const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P) && fits;
     hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         P.sampleBegin = sBegin;
