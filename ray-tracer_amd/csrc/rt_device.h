@@ -55,6 +55,7 @@ struct FrameParams {
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
     int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features
+    uint32_t logicalBlocks;      // (tile, sample) blocks of the current pass
     int32_t pairStackLds;        // shadow pass: entries of a wave's pair stack kept in LDS; the rest of the bound spills
     uint32_t* pairSpill;         // [pairSpillWaves][pairSpillEntries] spill area of the pair stacks
     uint32_t pairSpillEntries;

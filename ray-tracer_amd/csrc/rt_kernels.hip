@@ -31,29 +31,20 @@ __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long
     }
 }
 
-// Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  Renumber them so that every XCD
-// walks one contiguous run of tiles (one band of the frame) and its L2 keeps the part of the hierarchy
-// that band touches.  Bijective for any grid size.
-__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t n)
-{
-    const uint32_t q = n / 8, rem = n % 8, xcd = b % 8, idx = b / 8;
-    const uint32_t base = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    return base + idx;
-}
-
-// One lane = one (pixel, sample).  A block is one wave covering an 8x8 pixel tile at one sample index;
-// consecutive logical blocks are the samples of one tile, then the next tile.
+// One lane = one (pixel, sample).  A logical block is one wave's worth: an 8x8 pixel tile at one sample index;
+// consecutive logical blocks are the samples of one tile, then the next tile.  The render kernels are launched
+// with as many one-wave blocks as fit on the chip and each walks over logical blocks (launching one block per
+// logical block leaves the chip mostly empty: blocks this short are created more slowly than they finish).
 struct LaneId {
     int x, y, sidx;
     size_t pix;
     bool valid;
 };
-__device__ __forceinline__ LaneId lane_id(const FrameParams& P)
+__device__ __forceinline__ LaneId lane_id(const FrameParams& P, uint32_t logical)
 {
     const int lane = int(threadIdx.x);
     const int tilesX = (P.width + TILE - 1) / TILE;
     const int nS = P.sampleEnd - P.sampleBegin;
-    const uint32_t logical = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int tile = int(logical / uint32_t(nS));
     LaneId id;
     id.sidx = P.sampleBegin + int(logical % uint32_t(nS));
@@ -69,10 +60,11 @@ template <bool PRUNE, bool GLOSSY, bool COUNT, bool SPH>
 __global__ void __launch_bounds__(WAVE) k_render(const FrameParams P)
 {
     extern __shared__ uint2 lds_stack[];
-    const LaneId id = lane_id(P);
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
-    if (id.valid) {
+    for (uint32_t logical = blockIdx.x; logical < P.logicalBlocks; logical += gridDim.x) {
+        const LaneId id = lane_id(P, logical);
+        if (!id.valid) continue;
         bool live = true;
         if (P.f.depth_of_field && id.sidx > 0) live = P.dofFlags[id.pix] != 0;
         if (live) {
@@ -94,9 +86,10 @@ template <bool PRUNE, bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
 {
     extern __shared__ uint2 lds_stack[];
-    const LaneId id = lane_id(P);
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
+    for (uint32_t logical = blockIdx.x; logical < P.logicalBlocks; logical += gridDim.x) {
+    const LaneId id = lane_id(P, logical);
     int slot = -1;
     float t = FLT_MAX;
     if (id.valid) {
@@ -130,6 +123,7 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
             e.pad = 0;
             P.queue[at] = e;
         }
+    }
     }
     flush_counts(cnt, P.stats);
 }
@@ -685,35 +679,47 @@ size_t stack_bytes(const FrameParams& P, int threads)
     return size_t(threads) * size_t(depth) * sizeof(uint2);
 }
 
-template <bool PRUNE, bool GLOSSY>
-hipError_t launch_render_t(const FrameParams& P, dim3 grid, size_t lds, hipStream_t stream)
-{
-    if (P.scene.hasSpheres) {
-        if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true, true>), grid, dim3(WAVE), lds, stream, P);
-        else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false, true>), grid, dim3(WAVE), lds, stream, P);
-    } else {
-        if (P.countTests) hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, true, false>), grid, dim3(WAVE), lds, stream, P);
-        else hipLaunchKernelGGL((k_render<PRUNE, GLOSSY, false, false>), grid, dim3(WAVE), lds, stream, P);
-    }
-    return hipGetLastError();
-}
-
 // Blocks of `kernel` that can be resident on the whole chip at once (persistent kernels are sized to this).
 template <class K>
 uint32_t resident_blocks(K kernel, int threads, size_t lds)
 {
-    int perCu = 0, dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256u * 8u;
+    // the answer depends on (kernel, threads, lds, device); the last query of this kernel is remembered per thread
+    static thread_local struct { int threads, dev; size_t lds; uint32_t blocks; } last = { 0, -1, 0, 0 };
+    int perCu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256u * 8u;
+    if (last.dev == dev && last.threads == threads && last.lds == lds) return last.blocks;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 256u * 8u;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, lds) != hipSuccess || perCu < 1) perCu = 4;
-    return uint32_t(perCu) * uint32_t(prop.multiProcessorCount);
+    last = { threads, dev, lds, uint32_t(perCu) * uint32_t(cus) };
+    return last.blocks;
+}
+
+// Launches a render kernel with one-wave blocks: as many as are resident at once, or fewer if the pass is smaller.
+template <class K>
+void launch_walkers(K kernel, const FrameParams& P, size_t lds, hipStream_t stream)
+{
+    const uint32_t cap = resident_blocks(kernel, WAVE, lds);
+    hipLaunchKernelGGL(kernel, dim3(P.logicalBlocks < cap ? P.logicalBlocks : cap), dim3(WAVE), lds, stream, P);
+}
+
+template <bool PRUNE, bool GLOSSY>
+hipError_t launch_render_t(const FrameParams& P, size_t lds, hipStream_t stream)
+{
+    if (P.scene.hasSpheres) {
+        if (P.countTests) launch_walkers(k_render<PRUNE, GLOSSY, true, true>, P, lds, stream);
+        else launch_walkers(k_render<PRUNE, GLOSSY, false, true>, P, lds, stream);
+    } else {
+        if (P.countTests) launch_walkers(k_render<PRUNE, GLOSSY, true, false>, P, lds, stream);
+        else launch_walkers(k_render<PRUNE, GLOSSY, false, false>, P, lds, stream);
+    }
+    return hipGetLastError();
 }
 
 template <bool PRUNE>
-hipError_t launch_split_t(const FrameParams& P, dim3 grid, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev)
+hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev)
 {
-    if (P.countTests) hipLaunchKernelGGL((k_primary<PRUNE, true>), grid, dim3(WAVE), lds, stream, P);
-    else hipLaunchKernelGGL((k_primary<PRUNE, false>), grid, dim3(WAVE), lds, stream, P);
+    if (P.countTests) launch_walkers(k_primary<PRUNE, true>, P, lds, stream);
+    else launch_walkers(k_primary<PRUNE, false>, P, lds, stream);
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (P.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     if (ev) (void)hipEventRecord(ev[1], stream);
@@ -765,17 +771,17 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         P.sampleBegin = sBegin;
         P.sampleEnd = sEnd;
-        const dim3 grid(tiles * uint32_t(sEnd - sBegin));
+        P.logicalBlocks = tiles * uint32_t(sEnd - sBegin);
         if (split) {
             if ((e = hipMemsetAsync(P.queueCounters, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
             if (ev && splitRecorded) *splitRecorded = true;
-            return prune ? launch_split_t<true>(P, grid, gridDirect, lds, stream, ev) : launch_split_t<false>(P, grid, gridDirect, lds, stream, ev);
+            return prune ? launch_split_t<true>(P, gridDirect, lds, stream, ev) : launch_split_t<false>(P, gridDirect, lds, stream, ev);
         }
-        if (prune) return glossy ? launch_render_t<true, true>(P, grid, lds, stream) : launch_render_t<true, false>(P, grid, lds, stream);
-        return glossy ? launch_render_t<false, true>(P, grid, lds, stream) : launch_render_t<false, false>(P, grid, lds, stream);
+        if (prune) return glossy ? launch_render_t<true, true>(P, lds, stream) : launch_render_t<true, false>(P, lds, stream);
+        return glossy ? launch_render_t<false, true>(P, lds, stream) : launch_render_t<false, false>(P, lds, stream);
     };
     if (P.f.depth_of_field && !P.f.multiple_rays && P.samplesPerPixel > 1) {
         // the centre rays decide per pixel whether the lens rays are traced at all
