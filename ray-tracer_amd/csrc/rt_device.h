@@ -50,7 +50,7 @@ struct FrameParams {
     int32_t countTests;
     // two-kernel path: queue of primary hits, [0] = entries written, [1] = entries handed out
     struct HitEntry* queue;
-    unsigned long long* queueCounters; // [0] hits queued, [1] shadow packets handed out, [2] shadow work items queued
+    unsigned long long* queueCounters; // [0] hits queued, [1] shadow packets handed out, [2] shadow work items queued, [3] logical blocks handed out
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible

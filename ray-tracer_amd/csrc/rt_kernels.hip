@@ -80,54 +80,6 @@ __global__ void __launch_bounds__(WAVE) k_render(const FrameParams P)
     flush_counts(cnt, P.stats);
 }
 
-// Two-kernel path, first kernel: camera ray and closest hit.  A miss is final (sky or black); a hit goes to
-// the queue, appended with one atomic per wave so that the hits of a tile stay together.
-template <bool PRUNE, bool COUNT>
-__global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
-{
-    extern __shared__ uint2 lds_stack[];
-    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
-    Counts cnt;
-    for (uint32_t logical = blockIdx.x; logical < P.logicalBlocks; logical += gridDim.x) {
-    const LaneId id = lane_id(P, logical);
-    int slot = -1;
-    float t = FLT_MAX;
-    if (id.valid) {
-        Rng rng;
-        vec3 o, d;
-        sample_camera_ray(P, id.x, id.y, id.sidx, rng, o, d);
-        const RayD r = make_ray(o, d);
-        cnt.primary++;
-        slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
-        if (slot < 0) {
-            const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, d) : splat3(0.0f);
-            float* out = sample_slot(P, id.pix, id.sidx);
-            out[0] = c.x;
-            out[1] = c.y;
-            out[2] = c.z;
-        }
-    }
-    const unsigned long long hits = __ballot(slot >= 0);
-    if (hits) {
-        const int lane = int(threadIdx.x);
-        const int leader = __ffsll((long long)hits) - 1;
-        unsigned int base = 0;
-        if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[0], (unsigned long long)__popcll(hits));
-        base = __shfl(base, leader, 64);
-        if (slot >= 0) {
-            const unsigned int at = base + (unsigned int)__popcll(hits & ((1ull << lane) - 1ull));
-            HitEntry e;
-            e.work = uint32_t(id.sidx - P.sampleBegin) * uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width)) + uint32_t(id.pix);
-            e.t = t;
-            e.slot = slot;
-            e.pad = 0;
-            P.queue[at] = e;
-        }
-    }
-    }
-    flush_counts(cnt, P.stats);
-}
-
 // Recomputes the camera ray of a queued hit from its work id.
 __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e, uint32_t nPix, Rng& rng, RayD& r, size_t& pix, int& sidx)
 {
@@ -138,6 +90,43 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
     vec3 o, d;
     sample_camera_ray(P, x, y, sidx, rng, o, d);
     r = make_ray(o, d);
+}
+
+// Primary pass, second kernel: the closest hit of every camera ray the stream kernel (k_stream in primary
+// mode, below) found a primitive for, by the reference's own ordered, pruned traversal (traverse()).  One lane
+// per queued ray; the entry's distance and primitive slot are filled in place.  These rays all hit something,
+// so pruning keeps their traversals short and alike; the rays that hit nothing — among them the ones that
+// graze the surface through thousands of boxes — never get here.
+template <bool PRUNE, bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    Counts cnt;
+    const unsigned int nHits = (unsigned int)P.queueCounters[0];
+    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    for (unsigned int q = blockIdx.x * WAVE + threadIdx.x; q < nHits; q += gridDim.x * WAVE) {
+        HitEntry e = P.queue[q];
+        Rng rng;
+        RayD r;
+        size_t pix;
+        int sidx;
+        hit_ray(P, e, nPix, rng, r, pix, sidx);
+        float t = FLT_MAX;
+        e.slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
+        e.t = t;
+        P.queue[q] = e;
+        if (e.slot < 0) {
+            // cannot happen (the traversal meets the primitive the stream kernel found, or an earlier one, before
+            // anything is pruned); the later passes skip such an entry
+            const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
+            float* out = sample_slot(P, pix, sidx);
+            out[0] = c.x;
+            out[1] = c.y;
+            out[2] = c.z;
+        }
+    }
+    flush_counts(cnt, P.stats);
 }
 
 // Cull pass: one lane per queued hit.  Decides, for every shadow-casting light sample of the hit, whether the
@@ -155,7 +144,7 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     const unsigned int rounded = (nHits + 63u) & ~63u; // whole waves stay in the loop together
     uint32_t culled = 0;
     for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < rounded; q += gridDim.x * BLOCK) {
-        const bool live = q < nHits;
+        bool live = q < nHits;
         Rng rng;
         RayD r = make_ray(splat3(0.0f), splat3(1.0f));
         Surface s;
@@ -163,11 +152,14 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
         float t = 0.0f;
         if (live) {
             const HitEntry e = P.queue[q];
-            size_t pix;
-            int sidx;
-            hit_ray(P, e, nPix, rng, r, pix, sidx);
-            s = surface_at(P, r, e.t, e.slot);
-            t = e.t;
+            live = e.slot >= 0;
+            if (live) {
+                size_t pix;
+                int sidx;
+                hit_ray(P, e, nPix, rng, r, pix, sidx);
+                s = surface_at(P, r, e.t, e.slot);
+                t = e.t;
+            }
         }
         const vec3 point = r.o + (r.d * t);
         const vec3 N = normalize(s.normal);
@@ -221,8 +213,15 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     }
 }
 
-// Shadow pass: one any-hit query per queued (hit, light sample) — testVisibilityLightSample, reference
-// src/light.cpp:68-89 — traced by a wave as a STREAM OF (ray, node) PAIRS.
+// Any-hit queries traced by a wave as a STREAM OF (ray, node) PAIRS.  Two uses:
+//   shadow pass (PRIMARY = false): one query per queued (hit, light sample) — testVisibilityLightSample,
+//     reference src/light.cpp:68-89; the answer is the visibility bit;
+//   primary pass (PRIMARY = true): "does this camera ray meet any primitive at all".  Rays that do not are
+//     final; the others go to k_closest for the reference's ordered traversal.  The reference finds a hit
+//     exactly when some primitive below boxes the ray enters passes its test (nothing is pruned before the
+//     first acceptance), so the split changes no result; it takes the rays that skim the surface through
+//     thousands of boxes without hitting anything — the ones that would hold a whole wave for milliseconds —
+//     out of the per-lane kernel and spreads their boxes over all lanes here.
 //
 // The answer of an any-hit query ("is any primitive accepted before the light") is the OR over the nodes the
 // ray enters, and entering a node depends only on the ray's own box tests on the way down.  So the pairs
@@ -336,8 +335,8 @@ __device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, f32x2 o
     right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR) && (tinR < 0 ? toutR : tinR) < FLT_MAX;
 }
 
-template <bool COUNT>
-__global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
+template <bool COUNT, bool PRIMARY>
+__global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
 {
     // per ray: (ox oy oz ox) (oy oz ix iy) (iz ix iy iz) (dx dy dz flags), i = 1/d
     extern __shared__ f32x4 streamLds[];
@@ -350,52 +349,76 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
     Counts cnt;
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
-    const unsigned long long queued = P.queueCounters[2];
-    const unsigned long long nPackets = (queued + STREAM_RAYS - 1) / STREAM_RAYS;
+    const unsigned long long queued = PRIMARY ? 0ull : P.queueCounters[2];
+    const unsigned long long nPackets = PRIMARY ? (unsigned long long)P.logicalBlocks : (queued + STREAM_RAYS - 1) / STREAM_RAYS;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
+    // packets come from a cursor; camera-ray packets, many of which are over in a microsecond, several at a time
+    constexpr unsigned long long GRAB = PRIMARY ? 4ull : 1ull;
+    unsigned long long pkNext = 0, pkEnd = 0;
     while (true) {
-        unsigned long long pk = 0;
-        if (lane == 0) pk = atomicAdd(&P.queueCounters[1], 1ull);
-        pk = __shfl(pk, 0, 64);
-        if (pk >= nPackets) break;
+        if (pkNext == pkEnd) {
+            if (lane == 0) pkNext = atomicAdd(&P.queueCounters[PRIMARY ? 3 : 1], GRAB);
+            pkNext = __shfl(pkNext, 0, 64);
+            if (pkNext >= nPackets) break;
+            pkEnd = pkNext + GRAB < nPackets ? pkNext + GRAB : nPackets;
+        }
+        const unsigned long long pk = pkNext++;
         // ---- the packet's rays; the ones that pass the root gate start as pairs (ray, root)
         uint32_t count = 0, leafCount = 0;
         bool zeroClass = false; // some ray of the packet has a direction component in the zero class
         for (int h = 0; h < STREAM_RAYS / WAVE; h++) {
             const uint32_t rid = uint32_t(h * WAVE + lane);
-            const unsigned long long qi = pk * STREAM_RAYS + rid;
-            const bool have = qi < queued;
+            bool have = false;
             uint32_t work = 0;
             RayD r = make_ray(splat3(0.0f), splat3(1.0f));
             bool traced = false;
+            if (PRIMARY) {
+                // one logical block: an 8x8 pixel tile at one sample index
+                const LaneId id = lane_id(P, uint32_t(pk));
+                have = id.valid;
+                if (have) {
+                    Rng rng;
+                    vec3 o, d;
+                    sample_camera_ray(P, id.x, id.y, id.sidx, rng, o, d);
+                    r = make_ray(o, d);
+                    work = uint32_t(id.sidx - P.sampleBegin) * nPix + uint32_t(id.pix);
+                    cnt.primary++;
+                }
+            } else {
+                const unsigned long long qi = pk * STREAM_RAYS + rid;
+                have = qi < queued;
+                if (have) {
+                    work = P.shadowQueue[qi];
+                    const HitEntry e = P.queue[work / perHit];
+                    const int j = int(work % perHit);
+                    Rng rng;
+                    RayD cam;
+                    size_t pix;
+                    int sidx;
+                    hit_ray(P, e, nPix, rng, cam, pix, sidx);
+                    // which light and which of its samples: the last light whose first shadow sample is <= j
+                    int li = 0;
+                    for (int i = 0; i < P.nLights; i++)
+                        if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
+                    const LightDev& L = P.lights[li];
+                    const int k = j - L.shadowBase;
+                    vec3 position, color;
+                    light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                    const float epsilon = 0.00001f;
+                    const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
+                    r = make_ray(origin, position - origin);
+                    cnt.shadow++;
+                }
+            }
             if (have) {
-                work = P.shadowQueue[qi];
-                const HitEntry e = P.queue[work / perHit];
-                const int j = int(work % perHit);
-                Rng rng;
-                RayD cam;
-                size_t pix;
-                int sidx;
-                hit_ray(P, e, nPix, rng, cam, pix, sidx);
-                // which light and which of its samples: the last light whose first shadow sample is <= j
-                int li = 0;
-                for (int i = 0; i < P.nLights; i++)
-                    if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
-                const LightDev& L = P.lights[li];
-                const int k = j - L.shadowBase;
-                vec3 position, color;
-                light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
-                const float epsilon = 0.00001f;
-                const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
-                r = make_ray(origin, position - origin);
-                cnt.shadow++;
                 float tRoot;
                 if (COUNT) cnt.box++;
-                // root gate against the shadow ray's own bound t = 1 (…hierarchy.cpp:296-301)
-                traced = box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < 1.0f;
+                // root gate against the query's own bound (…hierarchy.cpp:296-301)
+                traced = S.numPrims > 0 && box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < tBound;
             }
             const uint32_t flags = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u) | (have ? RAY_PRESENT : 0u);
             zeroClass = zeroClass || __ballot(flags & 7u) != 0;
@@ -510,7 +533,7 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
                         more = prim_more(p);
                         if (COUNT) cnt.tri++;
                         float t;
-                        if (triangle_hit(r, p, 1.0f, t)) {
+                        if (triangle_hit(r, p, tBound, t)) {
                             atomicOr(reinterpret_cast<uint32_t*>(rec + 3) + 3, RAY_BLOCKED);
                             break;
                         }
@@ -522,12 +545,42 @@ __global__ void __launch_bounds__(WAVE) k_shadow(const FrameParams P)
         }
         for (int h = 0; h < STREAM_RAYS / WAVE; h++) {
             const uint32_t rid = uint32_t(h * WAVE + lane);
-            const uint32_t flags = __float_as_uint(rays[rid * 4 + 3].w);
-            if (flags & RAY_PRESENT) P.visibility[workOf[rid]] = (flags & RAY_BLOCKED) ? 0 : 1;
+            const f32x4 last = rays[rid * 4 + 3];
+            const uint32_t flags = __float_as_uint(last.w);
+            const bool present = flags & RAY_PRESENT, found = flags & RAY_BLOCKED;
+            if (!PRIMARY) {
+                if (present) P.visibility[workOf[rid]] = found ? 0 : 1;
+            } else {
+                // a camera ray that met no primitive is final (sky or black); the others queue up for k_closest,
+                // the rays of a tile next to each other (one atomic per wave)
+                const uint32_t work = workOf[rid];
+                if (present && !found) {
+                    const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, make3(last.x, last.y, last.z)) : splat3(0.0f);
+                    float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
+                    out[0] = c.x;
+                    out[1] = c.y;
+                    out[2] = c.z;
+                }
+                const unsigned long long hits = __ballot(present && found);
+                if (hits) {
+                    const int leader = __ffsll((long long)hits) - 1;
+                    unsigned int base = 0;
+                    if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[0], (unsigned long long)__popcll(hits));
+                    base = __shfl(base, leader, 64);
+                    if (present && found) {
+                        HitEntry e;
+                        e.work = work;
+                        e.t = 0.0f;
+                        e.slot = -1;
+                        e.pad = 0;
+                        P.queue[base + lanes_below(hits)] = e;
+                    }
+                }
+            }
         }
         lds_fence();
     }
-    flush_counts(cnt, P.stats, true);
+    flush_counts(cnt, P.stats, !PRIMARY);
 }
 
 // Shade pass: one lane per queued hit — direct lighting with the visibility bits of the shadow pass
@@ -538,6 +591,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
         const HitEntry e = P.queue[q];
+        if (e.slot < 0) continue;
         Rng rng;
         RayD r;
         size_t pix;
@@ -718,18 +772,28 @@ hipError_t launch_render_t(const FrameParams& P, size_t lds, hipStream_t stream)
 template <bool PRUNE>
 hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev)
 {
-    if (P.countTests) launch_walkers(k_primary<PRUNE, true>, P, lds, stream);
-    else launch_walkers(k_primary<PRUNE, false>, P, lds, stream);
+    const size_t streamLds = stream_lds_bytes(P.pairStackLds);
+    {
+        uint32_t cap = P.countTests ? resident_blocks(k_stream<true, true>, WAVE, streamLds) : resident_blocks(k_stream<false, true>, WAVE, streamLds);
+        if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
+        const dim3 g(P.logicalBlocks < cap ? P.logicalBlocks : cap);
+        if (P.countTests) hipLaunchKernelGGL((k_stream<true, true>), g, dim3(WAVE), streamLds, stream, P);
+        else hipLaunchKernelGGL((k_stream<false, true>), g, dim3(WAVE), streamLds, stream, P);
+        // the queue length is only known on the device: size the grid for every resident wave
+        const uint32_t walkers = P.countTests ? resident_blocks(k_closest<PRUNE, true>, WAVE, lds) : resident_blocks(k_closest<PRUNE, false>, WAVE, lds);
+        const dim3 gc(gridDirect.x < walkers ? gridDirect.x : walkers);
+        if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, stream, P);
+        else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), lds, stream, P);
+    }
     if (ev) (void)hipEventRecord(ev[0], stream);
     if (P.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (P.shadowSamplesPerHit > 0) {
-        const size_t laneLds = stream_lds_bytes(P.pairStackLds);
-        uint32_t cap = P.countTests ? resident_blocks(k_shadow<true>, WAVE, laneLds) : resident_blocks(k_shadow<false>, WAVE, laneLds);
+        uint32_t cap = P.countTests ? resident_blocks(k_stream<true, false>, WAVE, streamLds) : resident_blocks(k_stream<false, false>, WAVE, streamLds);
         if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
         const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
-        if (P.countTests) hipLaunchKernelGGL(k_shadow<true>, g, dim3(WAVE), laneLds, stream, P);
-        else hipLaunchKernelGGL(k_shadow<false>, g, dim3(WAVE), laneLds, stream, P);
+        if (P.countTests) hipLaunchKernelGGL((k_stream<true, false>), g, dim3(WAVE), streamLds, stream, P);
+        else hipLaunchKernelGGL((k_stream<false, false>), g, dim3(WAVE), streamLds, stream, P);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
     hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
