@@ -491,6 +491,12 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
             return v < 64 ? 64 : v;
         }();
         P.pairStackLds = pairStackLds;
+        static const int primaryBudget = [] {
+            const char* e = std::getenv("RT_PRIMARY_BUDGET"); // tuning / test knob; default chosen by measurement
+            const int v = e ? std::atoi(e) : 64;
+            return v < 1 ? 1 : v;
+        }();
+        P.primaryBudget = primaryBudget;
     }
 
     int spp = 1;

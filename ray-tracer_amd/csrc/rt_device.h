@@ -50,8 +50,10 @@ struct FrameParams {
     int32_t countTests;
     // two-kernel path: queue of primary hits, [0] = entries written, [1] = entries handed out
     struct HitEntry* queue;
-    unsigned long long* queueCounters; // [0] hits queued, [1] shadow packets handed out, [2] shadow work items queued, [3] logical blocks handed out
-    uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray
+    unsigned long long* queueCounters; // [0] hits queued, [1] shadow packets handed out, [2] shadow work items queued, [3] packets of given-up camera rays handed out, [4] camera rays that gave up
+    uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
+                                       // primary pass: the camera rays (sample * pixels + pixel) that gave up
+    int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
     int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features
@@ -231,8 +233,12 @@ struct Stack {
 //   - a triangle is accepted when strictly closer than the current distance, so ties keep the first found.
 // Returns the slot of the accepted primitive (or -1) and updates tmax.  An any-hit query returns at the
 // first accepted triangle: the reference's boolean is the same because acceptance is what sets it.
-template <bool PRUNE, bool ANY, bool COUNT, bool SPH>
-__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt, Attr& attr)
+//
+// BUDGET: a query that has visited `budget` inner nodes without accepting anything gives up and returns
+// TRAVERSE_GAVE_UP; the caller hands it to a kernel that shares such a ray's boxes among all lanes.
+constexpr int TRAVERSE_GAVE_UP = -2;
+template <bool PRUNE, bool ANY, bool COUNT, bool SPH, bool BUDGET = false>
+__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt, Attr& attr, int budget = 0)
 {
     attr.slot = -1;
     attr.t = tmax;
@@ -253,6 +259,7 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
             bool descend = true;
             if (PRUNE) descend = !(curT > (SPH ? bestTri : (hit >= 0 ? tmax : FLT_MAX)));
             if (descend) {
+                if (BUDGET && hit < 0 && --budget < 0) return TRAVERSE_GAVE_UP;
                 const Rec64 nd = load_rec(&S.nodes[cur]);
                 float tL, tR;
                 if (COUNT) cnt.box += 2;

@@ -16,6 +16,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// set bits of m in the lanes below this one
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
+}
+
 __device__ __forceinline__ void flush_counts(const Counts& c, unsigned long long* stats, bool shadowPass = false)
 {
     if (!stats) return;
@@ -92,11 +98,76 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
     r = make_ray(o, d);
 }
 
-// Primary pass, second kernel: the closest hit of every camera ray the stream kernel (k_stream in primary
-// mode, below) found a primitive for, by the reference's own ordered, pruned traversal (traverse()).  One lane
-// per queued ray; the entry's distance and primitive slot are filled in place.  These rays all hit something,
-// so pruning keeps their traversals short and alike; the rays that hit nothing — among them the ones that
-// graze the surface through thousands of boxes — never get here.
+// Primary pass.  Three kernels:
+//   k_primary   camera ray and closest hit by the reference's ordered, pruned traversal, one lane per ray — with
+//               a budget: a ray that has visited P.primaryBudget inner nodes and still found nothing gives up and
+//               is queued.  Such rays skim along the surface through thousands of boxes, nothing prunes them,
+//               and one of them would hold its whole wave for milliseconds.
+//   k_stream    (primary mode, below) answers "does the ray meet any primitive at all" for the queued rays, with
+//               the boxes of each ray spread over all lanes.  Most of them meet nothing and are final.  The
+//               reference finds a hit exactly when some primitive below boxes the ray enters passes its test
+//               (nothing is pruned before the first acceptance), so this changes no result.
+//   k_closest   the unbudgeted traversal for the few queued rays that do meet something.
+// A miss is final (sky or black); a hit goes to the hit queue, appended with one atomic per wave so that the hits
+// of a tile stay together.
+template <bool PRUNE, bool COUNT>
+__global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    Counts cnt;
+    const int lane = int(threadIdx.x);
+    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    for (uint32_t logical = blockIdx.x; logical < P.logicalBlocks; logical += gridDim.x) {
+        const LaneId id = lane_id(P, logical);
+        int slot = -1;
+        float t = FLT_MAX;
+        if (id.valid) {
+            Rng rng;
+            vec3 o, d;
+            sample_camera_ray(P, id.x, id.y, id.sidx, rng, o, d);
+            const RayD r = make_ray(o, d);
+            cnt.primary++;
+            Attr attr;
+            slot = traverse<PRUNE, false, COUNT, false, true>(P.scene, r, t, st, cnt, attr, P.primaryBudget);
+            if (slot == -1) {
+                const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, d) : splat3(0.0f);
+                float* out = sample_slot(P, id.pix, id.sidx);
+                out[0] = c.x;
+                out[1] = c.y;
+                out[2] = c.z;
+            }
+        }
+        const uint32_t work = uint32_t(id.sidx - P.sampleBegin) * nPix + uint32_t(id.pix);
+        const unsigned long long hits = __ballot(slot >= 0);
+        if (hits) {
+            const int leader = __ffsll((long long)hits) - 1;
+            unsigned int base = 0;
+            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[0], (unsigned long long)__popcll(hits));
+            base = __shfl(base, leader, 64);
+            if (slot >= 0) {
+                HitEntry e;
+                e.work = work;
+                e.t = t;
+                e.slot = slot;
+                e.pad = 0;
+                P.queue[base + lanes_below(hits)] = e;
+            }
+        }
+        const unsigned long long gaveUp = __ballot(slot == TRAVERSE_GAVE_UP);
+        if (gaveUp) {
+            const int leader = __ffsll((long long)gaveUp) - 1;
+            unsigned int base = 0;
+            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[4], (unsigned long long)__popcll(gaveUp));
+            base = __shfl(base, leader, 64);
+            if (slot == TRAVERSE_GAVE_UP) P.shadowQueue[base + lanes_below(gaveUp)] = work;
+        }
+    }
+    flush_counts(cnt, P.stats);
+}
+
+// Primary pass, third kernel: one lane per hit-queue entry the stream kernel appended without a primitive
+// (slot < 0); the entry's distance and primitive slot are filled in place.
 template <bool PRUNE, bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
 {
@@ -107,6 +178,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     for (unsigned int q = blockIdx.x * WAVE + threadIdx.x; q < nHits; q += gridDim.x * WAVE) {
         HitEntry e = P.queue[q];
+        if (e.slot >= 0) continue;
         Rng rng;
         RayD r;
         size_t pix;
@@ -216,12 +288,8 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // Any-hit queries traced by a wave as a STREAM OF (ray, node) PAIRS.  Two uses:
 //   shadow pass (PRIMARY = false): one query per queued (hit, light sample) — testVisibilityLightSample,
 //     reference src/light.cpp:68-89; the answer is the visibility bit;
-//   primary pass (PRIMARY = true): "does this camera ray meet any primitive at all".  Rays that do not are
-//     final; the others go to k_closest for the reference's ordered traversal.  The reference finds a hit
-//     exactly when some primitive below boxes the ray enters passes its test (nothing is pruned before the
-//     first acceptance), so the split changes no result; it takes the rays that skim the surface through
-//     thousands of boxes without hitting anything — the ones that would hold a whole wave for milliseconds —
-//     out of the per-lane kernel and spreads their boxes over all lanes here.
+//   primary pass (PRIMARY = true): "does this camera ray meet any primitive at all", for the rays that gave up
+//     in k_primary (see there).  Rays that do not are final; the others go to k_closest.
 //
 // The answer of an any-hit query ("is any primitive accepted before the light") is the OR over the nodes the
 // ray enters, and entering a node depends only on the ray's own box tests on the way down.  So the pairs
@@ -249,7 +317,7 @@ constexpr int STREAM_REF_BITS = 25;                       // pair = ray index (7
 constexpr uint32_t STREAM_REF_MASK = (1u << STREAM_REF_BITS) - 1u;
 constexpr int STREAM_PER_LEVEL = 128;                     // stack entries per inner tree level
 constexpr int STREAM_LEAF_CAP = 192;                      // < 64 waiting + 128 from one step
-constexpr uint32_t RAY_BLOCKED = 8u, RAY_PRESENT = 16u;   // flag bits next to the three zero-direction bits
+constexpr uint32_t RAY_BLOCKED = 8u;                      // flag bit next to the three zero-direction bits
 
 constexpr int STREAM_STAGE_STRIDE = 1024 + 16;            // bytes between the four quarter-wave images of the record stage
 
@@ -281,12 +349,6 @@ struct PairStack {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// set bits of m in the lanes below / above this one
-__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
-{
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u));
-}
 
 // One 64-byte record per lane (byte offset `off` from `base`, any valid offset for lanes that need nothing),
 // fetched so that a load instruction touches 16 cache lines instead of 64: the four lanes of a quad fetch the
@@ -341,55 +403,64 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
     // per ray: (ox oy oz ox) (oy oz ix iy) (iz ix iy iz) (dx dy dz flags), i = 1/d
     extern __shared__ f32x4 streamLds[];
     f32x4* rays = streamLds;
-    char* stage = reinterpret_cast<char*>(rays + STREAM_RAYS * 4);
+    constexpr int RAY_SLOTS = STREAM_RAYS;
+    char* stage = reinterpret_cast<char*>(rays + RAY_SLOTS * 4);
     uint32_t* workOf = reinterpret_cast<uint32_t*>(stage + 4 * STREAM_STAGE_STRIDE);
-    uint32_t* leafPool = workOf + STREAM_RAYS;
+    uint32_t* leafPool = workOf + RAY_SLOTS;
     const PairStack pool { leafPool + STREAM_LEAF_CAP, P.pairSpill + size_t(blockIdx.x) * P.pairSpillEntries, uint32_t(P.pairStackLds) };
     const int lane = int(threadIdx.x);
     Counts cnt;
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
-    const unsigned long long queued = PRIMARY ? 0ull : P.queueCounters[2];
-    const unsigned long long nPackets = PRIMARY ? (unsigned long long)P.logicalBlocks : (queued + STREAM_RAYS - 1) / STREAM_RAYS;
+    const unsigned long long queued = P.queueCounters[PRIMARY ? 4 : 2];
+    const unsigned long long nPackets = (queued + STREAM_RAYS - 1) / STREAM_RAYS;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
-    // packets come from a cursor; camera-ray packets, many of which are over in a microsecond, several at a time
-    constexpr unsigned long long GRAB = PRIMARY ? 4ull : 1ull;
+    // Packets of 64 consecutive queued queries come from a cursor; a wave whose packet left no ray behind the root
+    // gate takes another one before it starts streaming.
+    constexpr unsigned long long GRAB = 1ull;
+    constexpr uint32_t SLOTS = STREAM_RAYS;
     unsigned long long pkNext = 0, pkEnd = 0;
-    while (true) {
-        if (pkNext == pkEnd) {
-            if (lane == 0) pkNext = atomicAdd(&P.queueCounters[PRIMARY ? 3 : 1], GRAB);
-            pkNext = __shfl(pkNext, 0, 64);
-            if (pkNext >= nPackets) break;
-            pkEnd = pkNext + GRAB < nPackets ? pkNext + GRAB : nPackets;
-        }
-        const unsigned long long pk = pkNext++;
-        // ---- the packet's rays; the ones that pass the root gate start as pairs (ray, root)
+    bool exhausted = false;
+    while (!exhausted) {
+        uint32_t used = 0; // ray slots taken
         uint32_t count = 0, leafCount = 0;
         bool zeroClass = false; // some ray of the packet has a direction component in the zero class
-        for (int h = 0; h < STREAM_RAYS / WAVE; h++) {
-            const uint32_t rid = uint32_t(h * WAVE + lane);
+        while (used + WAVE <= SLOTS) {
+            if (pkNext == pkEnd) {
+                if (lane == 0) pkNext = atomicAdd(&P.queueCounters[PRIMARY ? 3 : 1], GRAB);
+                pkNext = __shfl(pkNext, 0, 64);
+                if (pkNext >= nPackets) {
+                    pkEnd = pkNext;
+                    exhausted = true;
+                    break;
+                }
+                pkEnd = pkNext + GRAB < nPackets ? pkNext + GRAB : nPackets;
+            }
+            const unsigned long long pk = pkNext++;
+            // ---- 64 queries; the ones that pass the root gate start as pairs (ray, root)
             bool have = false;
             uint32_t work = 0;
             RayD r = make_ray(splat3(0.0f), splat3(1.0f));
             bool traced = false;
             if (PRIMARY) {
-                // one logical block: an 8x8 pixel tile at one sample index
-                const LaneId id = lane_id(P, uint32_t(pk));
-                have = id.valid;
+                // 64 camera rays that gave up in k_primary
+                const unsigned long long qi = pk * STREAM_RAYS + uint32_t(lane);
+                have = qi < queued;
                 if (have) {
+                    work = P.shadowQueue[qi];
+                    HitEntry e;
+                    e.work = work;
                     Rng rng;
-                    vec3 o, d;
-                    sample_camera_ray(P, id.x, id.y, id.sidx, rng, o, d);
-                    r = make_ray(o, d);
-                    work = uint32_t(id.sidx - P.sampleBegin) * nPix + uint32_t(id.pix);
-                    cnt.primary++;
+                    size_t pix;
+                    int sidx;
+                    hit_ray(P, e, nPix, rng, r, pix, sidx);
                 }
             } else {
-                const unsigned long long qi = pk * STREAM_RAYS + rid;
+                const unsigned long long qi = pk * STREAM_RAYS + uint32_t(lane);
                 have = qi < queued;
                 if (have) {
                     work = P.shadowQueue[qi];
@@ -420,22 +491,36 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 // root gate against the query's own bound (…hierarchy.cpp:296-301)
                 traced = S.numPrims > 0 && box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < tBound;
             }
-            const uint32_t flags = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u) | (have ? RAY_PRESENT : 0u);
-            zeroClass = zeroClass || __ballot(flags & 7u) != 0;
-            f32x4* rec = rays + rid * 4;
-            rec[0] = f32x4 { r.o.x, r.o.y, r.o.z, r.o.x };
-            rec[1] = f32x4 { r.o.y, r.o.z, r.inv.x, r.inv.y };
-            rec[2] = f32x4 { r.inv.z, r.inv.x, r.inv.y, r.inv.z };
-            rec[3] = f32x4 { r.d.x, r.d.y, r.d.z, __uint_as_float(flags) };
-            workOf[rid] = work;
-            const unsigned long long m = __ballot(traced);
-            if (S.rootRef >= 0) {
-                if (traced) pool.put(count + lanes_below(m), (rid << STREAM_REF_BITS) | uint32_t(S.rootRef));
-                count += uint32_t(__popcll(m));
-            } else {
-                if (traced) leafPool[leafCount + lanes_below(m)] = (rid << STREAM_REF_BITS) | uint32_t(~S.rootRef);
-                leafCount += uint32_t(__popcll(m));
+            // a query stopped at the root is answered here; the others take a ray slot each
+            if (have && !traced) {
+                if (PRIMARY) {
+                    const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
+                    float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
+                    out[0] = c.x;
+                    out[1] = c.y;
+                    out[2] = c.z;
+                } else {
+                    P.visibility[work] = 1;
+                }
             }
+            const unsigned long long m = __ballot(traced);
+            if (traced) {
+                const uint32_t rid = used + lanes_below(m);
+                const uint32_t flags = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u);
+                f32x4* rec = rays + rid * 4;
+                rec[0] = f32x4 { r.o.x, r.o.y, r.o.z, r.o.x };
+                rec[1] = f32x4 { r.o.y, r.o.z, r.inv.x, r.inv.y };
+                rec[2] = f32x4 { r.inv.z, r.inv.x, r.inv.y, r.inv.z };
+                rec[3] = f32x4 { r.d.x, r.d.y, r.d.z, __uint_as_float(flags) };
+                workOf[rid] = work;
+                if (S.rootRef >= 0) pool.put(count + rid - used, (rid << STREAM_REF_BITS) | uint32_t(S.rootRef));
+                else leafPool[leafCount + rid - used] = (rid << STREAM_REF_BITS) | uint32_t(~S.rootRef);
+            }
+            zeroClass = zeroClass || __ballot(traced && (r.zx || r.zy || r.zz)) != 0;
+            const uint32_t n = uint32_t(__popcll(m));
+            if (S.rootRef >= 0) count += n;
+            else leafCount += n;
+            used += n;
         }
         lds_fence();
         // ---- the stream
@@ -543,17 +628,16 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
             }
             __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
         }
-        for (int h = 0; h < STREAM_RAYS / WAVE; h++) {
-            const uint32_t rid = uint32_t(h * WAVE + lane);
-            const f32x4 last = rays[rid * 4 + 3];
-            const uint32_t flags = __float_as_uint(last.w);
-            const bool present = flags & RAY_PRESENT, found = flags & RAY_BLOCKED;
+        for (uint32_t rid = uint32_t(lane); rid < ((used + 63u) & ~63u); rid += WAVE) {
+            const bool present = rid < used;
+            const f32x4 last = rays[(present ? rid : 0u) * 4 + 3];
+            const bool found = __float_as_uint(last.w) & RAY_BLOCKED;
+            const uint32_t work = workOf[present ? rid : 0u];
             if (!PRIMARY) {
-                if (present) P.visibility[workOf[rid]] = found ? 0 : 1;
+                if (present) P.visibility[work] = found ? 0 : 1;
             } else {
                 // a camera ray that met no primitive is final (sky or black); the others queue up for k_closest,
                 // the rays of a tile next to each other (one atomic per wave)
-                const uint32_t work = workOf[rid];
                 if (present && !found) {
                     const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, make3(last.x, last.y, last.z)) : splat3(0.0f);
                     float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
@@ -774,12 +858,15 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
 {
     const size_t streamLds = stream_lds_bytes(P.pairStackLds);
     {
+        if (P.countTests) launch_walkers(k_primary<PRUNE, true>, P, lds, stream);
+        else launch_walkers(k_primary<PRUNE, false>, P, lds, stream);
+        // how many rays gave up, and how many of those meet a primitive, is only known on the device: both kernels
+        // get a grid that covers every resident wave
         uint32_t cap = P.countTests ? resident_blocks(k_stream<true, true>, WAVE, streamLds) : resident_blocks(k_stream<false, true>, WAVE, streamLds);
         if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
-        const dim3 g(P.logicalBlocks < cap ? P.logicalBlocks : cap);
+        const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
         if (P.countTests) hipLaunchKernelGGL((k_stream<true, true>), g, dim3(WAVE), streamLds, stream, P);
         else hipLaunchKernelGGL((k_stream<false, true>), g, dim3(WAVE), streamLds, stream, P);
-        // the queue length is only known on the device: size the grid for every resident wave
         const uint32_t walkers = P.countTests ? resident_blocks(k_closest<PRUNE, true>, WAVE, lds) : resident_blocks(k_closest<PRUNE, false>, WAVE, lds);
         const dim3 gc(gridDirect.x < walkers ? gridDirect.x : walkers);
         if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, stream, P);
@@ -837,7 +924,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
         P.sampleEnd = sEnd;
         P.logicalBlocks = tiles * uint32_t(sEnd - sBegin);
         if (split) {
-            if ((e = hipMemsetAsync(P.queueCounters, 0, 4 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(P.queueCounters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
