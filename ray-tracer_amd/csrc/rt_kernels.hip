@@ -303,10 +303,10 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // never share a step.  Rays live in LDS too (a lane works for a different ray every step); a ray that has
 // been blocked gets a flag in its record, and its remaining pairs are dropped when popped.
 //
-// Stack bound.  Lane 0 pops the top entry, lane 1 the one below, and so on; the children are pushed in
-// reverse lane order (those of lane 63 lowest).  By induction the tree levels of the entries never decrease
-// from the bottom of the stack to the top: the popped entries are the deepest ones, their levels do not
-// increase with the lane index, and every child is deeper than everything left below.  Hence a step pops
+// Stack bound.  The top k <= 64 entries are popped, the topmost by lane k-1, the one below it by lane k-2, and so
+// on; the children are pushed in lane order (those of lane 0 lowest).  By induction the tree levels of the
+// entries never decrease from the bottom of the stack to the top: the popped entries are the deepest ones, their
+// levels do not decrease with the lane index, and every child is deeper than everything left below.  Hence a step pops
 // level-l entries only together with ALL deeper entries, the level l+1 then consists of the new children
 // alone, and no level ever holds more than the 128 children of one step: 128 entries per inner level suffice.
 //
@@ -529,19 +529,22 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 // box step: the top 64 pairs
                 const uint32_t k = count < 64u ? count : 64u;
                 const bool got = uint32_t(lane) < k;
-                const bool inLds = count + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
+                const bool inLds = count - k + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
                 uint32_t e = 0u;
-                if (inLds) {
-                    if (got) e = pool.lds[count - 1u - uint32_t(lane)];
-                } else {
-                    if (got) e = pool.get(count - 1u - uint32_t(lane));
-                }
                 count -= k;
-                stage_records(S.nodes, (e & STREAM_REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
+                if (inLds) {
+                    if (got) e = pool.lds[count + uint32_t(lane)];
+                } else {
+                    if (got) e = pool.get(count + uint32_t(lane));
+                }
+                // the ray's record is read before the node loads are issued so that both are in flight together (an LDS
+                // read placed after them would be made to wait for them)
                 const uint32_t rid = e >> STREAM_REF_BITS;
                 const f32x4* rec = rays + rid * 4;
                 const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 const uint32_t flags = __float_as_uint(rec[3].w);
+                asm volatile("" ::: "memory");
+                stage_records(S.nodes, (e & STREAM_REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
                 bool vL = false, vR = false;
                 int32_t refL = 0, refR = 0;
                 stage_wait();
@@ -564,11 +567,11 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                     refR = __float_as_int(refs.y);
                 }
                 const uint32_t tag = rid << STREAM_REF_BITS;
-                // children that are inner nodes go back on the stack, those of higher lanes lower
+                // children that are inner nodes go back on the stack, those of higher lanes higher
                 const bool iL = vL && refL >= 0, iR = vR && refR >= 0;
-                const unsigned long long bL = __ballot(iL), bR = __ballot(iR);
+                const unsigned long long bL = __builtin_amdgcn_ballot_w64(iL), bR = __builtin_amdgcn_ballot_w64(iR);
                 const uint32_t nL = uint32_t(__popcll(bL)), nR = uint32_t(__popcll(bR));
-                const uint32_t at = count + (nL - lanes_below(bL) - (iL ? 1u : 0u)) + (nR - lanes_below(bR) - (iR ? 1u : 0u));
+                const uint32_t at = count + lanes_below(bL) + lanes_below(bR);
                 if (inLds) {
                     if (iL) pool.lds[at] = tag | uint32_t(refL);
                     if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | uint32_t(refR);
@@ -579,7 +582,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 count += nL + nR;
                 // children that are leaves: to the primitive pool
                 const bool lL = vL && refL < 0, lR = vR && refR < 0;
-                const unsigned long long bLL = __ballot(lL), bLR = __ballot(lR);
+                const unsigned long long bLL = __builtin_amdgcn_ballot_w64(lL), bLR = __builtin_amdgcn_ballot_w64(lR);
                 if (lL) leafPool[leafCount + lanes_below(bLL)] = tag | uint32_t(~refL);
                 leafCount += uint32_t(__popcll(bLL));
                 if (lR) leafPool[leafCount + lanes_below(bLR)] = tag | uint32_t(~refR);
