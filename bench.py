@@ -146,15 +146,15 @@ def main():
     cst = render_frame(count_params)
     torch.cuda.synchronize()
     my_pixels = WIDTH * sum(tiling.block_rows(b, HEIGHT)[1] - tiling.block_rows(b, HEIGHT)[0] for b in my_blocks)
-    # The dominant kernel is k_shadow (the shadow-ray packets).  Its algorithmic bytes per launch: 28 B ray in +
-    # 16 B result out per shadow ray, 32 B per ray/box test and 36 B per ray/triangle test it performs.  Its launch
+    # The dominant kernel is the shadow pass, k_stream<COUNT=false, PRIMARY=false>.  Its algorithmic bytes per launch:
+    # 28 B ray in + 16 B result out per shadow ray, 32 B per ray/box test and 36 B per ray/triangle test it performs.  Its launch
     # duration comes from HIP events recorded on the launch stream around it inside rt_render.  With N > 1 a rank
     # issues several rt_render calls per frame, the per-kernel split is not recorded, and the whole call is used.
     all_bytes = algorithmic_bytes(cst, my_pixels)
     all_flops = algorithmic_flops(cst)
     have_split = shadow_ms > 0.0
     if have_split:
-        dom_name = "k_shadow"
+        dom_name = "k_stream<false, false> (shadow pass)"
         dom_bytes = 44 * cst.shadow_rays + 32 * cst.shadow_box_tests + 36 * cst.shadow_triangle_tests
         dom_flops = 27 * cst.shadow_box_tests + 150 * cst.shadow_triangle_tests
         dom_s = shadow_ms / args.steps / 1e3
@@ -202,8 +202,9 @@ def main():
                 "traffic": measured_traffic(world),
                 "kernel_ms": dom_s * 1e3,
                 "algorithmic_bytes_per_launch": dom_bytes,
-                "note": "the working set (hierarchy + primitives, a few MB) is cache resident, so HBM is the nominal "
-                        "denominator only; the kernel is bound by VALU/SALU issue under low lane utilisation, see valu",
+                "note": "the working set (hierarchy + primitives, about 10 MB) is cache resident, so HBM is the nominal "
+                        "denominator only and the fraction can exceed 1; the kernel is bound by VALU issue (about 105 "
+                        "vector instructions per 64 ray/node pairs), see valu and profiles/",
                 "valu": {"achieved": dom_flops / dom_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": dom_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS},
                 "all_kernels": {"kernel_ms": avg_kernel_s * 1e3, "primary_ms": primary_ms / args.steps, "shadow_ms": shadow_ms / args.steps,
@@ -222,15 +223,15 @@ def main():
 
 
 def measured_traffic(world):
-    """HBM bytes per frame from the committed rocprofv3 PMC passes of this same command (profiles/<tag>/traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as the gfx950 note prescribes), or None when
-    no measurement of the current kernels is committed."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, in KiB, FETCH_SIZE doubled as
+    prescribed for gfx950), or None when no measurement of the current kernels is committed."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_frame")
+            return json.load(f).get("dominant_kernel_hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 

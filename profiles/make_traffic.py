@@ -1,0 +1,39 @@
+"""profiles/make_traffic.py <tag>: writes profiles/traffic.json from profiles/<tag>/summary.txt (the FETCH_SIZE and
+WRITE_SIZE passes of profiles/run_profile.sh).  Check on a known byte count: k_resolve reads 16 sample planes of
+1920 x 1080 x 12 B = 398 MB, and 2 x FETCH_SIZE x 1024 gives 398 MB."""
+import json
+import os
+import re
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+tag = sys.argv[1]
+txt = open(os.path.join(HERE, tag, "summary.txt")).read()
+
+
+def grab(section, counter):
+    sec = txt.split("== PMC pass %s" % section)[1].split("== PMC")[0]
+    out = {}
+    for line in sec.splitlines():
+        m = re.search(r"(k_\w+(?:<[^>]*>)?).*?dispatches=\s*(\d+).*?%s=([\d.e+]+)" % counter, line)
+        if m:
+            out[m.group(1)] = float(m.group(3))
+    return out
+
+
+fetch, write = grab("fetch", "FETCH_SIZE"), grab("write", "WRITE_SIZE")
+per_kernel = {k: {"fetch_KiB": fetch[k], "write_KiB": write.get(k, 0.0),
+                  "hbm_bytes_per_launch": int(2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024)} for k in fetch}
+frame = ["k_primary<true, false>", "k_stream<false, true>", "k_closest<true, false>", "k_cull", "k_stream<false, false>", "k_shade", "k_resolve"]
+doc = {
+    "source": "profiles/%s/summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, of `python3 bench.py "
+              "--steps 3 --warmup 1 --no-cpu-baseline` on one MI355X; per-dispatch averages" % tag,
+    "units": "FETCH_SIZE and WRITE_SIZE are reported in KiB; bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-byte read "
+             "requests as 64 bytes) + WRITE_SIZE x 1024",
+    "per_kernel": per_kernel,
+    "dominant_kernel": "k_stream<false, false>",
+    "dominant_kernel_hbm_bytes_per_launch": per_kernel["k_stream<false, false>"]["hbm_bytes_per_launch"],
+    "hbm_bytes_per_frame": sum(per_kernel[k]["hbm_bytes_per_launch"] for k in frame if k in per_kernel),
+}
+json.dump(doc, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
+print(doc["dominant_kernel_hbm_bytes_per_launch"], doc["hbm_bytes_per_frame"])
