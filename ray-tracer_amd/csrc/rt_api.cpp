@@ -519,7 +519,7 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
         const size_t want = nPix * size_t(spp);
         const size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
         RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
-        RT_HIP(b->queueCounters.reserve(64));
+        RT_HIP(b->queueCounters.reserve(Q_COUNT * sizeof(unsigned long long)));
         const size_t items = cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1);
         if (items >= (size_t(1) << 32)) return fail(RT_ERR_LIMIT, "too many shadow samples per pass (pixels x samples x light samples must stay below 2^32)");
         RT_HIP(b->visibility.reserve(items));

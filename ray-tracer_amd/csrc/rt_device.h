@@ -50,7 +50,7 @@ struct FrameParams {
     int32_t countTests;
     // two-kernel path: queue of primary hits, [0] = entries written, [1] = entries handed out
     struct HitEntry* queue;
-    unsigned long long* queueCounters; // [0] hits queued, [1] shadow packets handed out, [2] shadow work items queued, [3] packets of given-up camera rays handed out, [4] camera rays that gave up
+    unsigned long long* queueCounters; // Q_COUNT counters of the current pass, see below
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
                                        // primary pass: the camera rays (sample * pixels + pixel) that gave up
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
@@ -62,6 +62,17 @@ struct FrameParams {
     uint32_t* pairSpill;         // [pairSpillWaves][pairSpillEntries] spill area of the pair stacks
     uint32_t pairSpillEntries;
     uint32_t pairSpillWaves;
+};
+
+// Device counters of a pass.  Each sits in a 128-byte line of its own: atomics on one line are served one after the
+// other, and the kernels of a pass hammer different counters at the same time.
+enum {
+    Q_HITS = 0,              // hit-queue entries
+    Q_SHADOW_PACKETS = 16,   // shadow packets handed out
+    Q_SHADOW_ITEMS = 32,     // shadow work items queued
+    Q_GAVE_UP_PACKETS = 48,  // packets of given-up camera rays handed out
+    Q_GAVE_UP = 64,          // camera rays that gave up
+    Q_COUNT = 80
 };
 
 struct Counts {

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
         if (hits) {
             const int leader = __ffsll((long long)hits) - 1;
             unsigned int base = 0;
-            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[0], (unsigned long long)__popcll(hits));
+            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(hits));
             base = __shfl(base, leader, 64);
             if (slot >= 0) {
                 HitEntry e;
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
         if (gaveUp) {
             const int leader = __ffsll((long long)gaveUp) - 1;
             unsigned int base = 0;
-            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[4], (unsigned long long)__popcll(gaveUp));
+            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_GAVE_UP], (unsigned long long)__popcll(gaveUp));
             base = __shfl(base, leader, 64);
             if (slot == TRAVERSE_GAVE_UP) P.shadowQueue[base + lanes_below(gaveUp)] = work;
         }
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
     extern __shared__ uint2 lds_stack[];
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
-    const unsigned int nHits = (unsigned int)P.queueCounters[0];
+    const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     for (unsigned int q = blockIdx.x * WAVE + threadIdx.x; q < nHits; q += gridDim.x * WAVE) {
         HitEntry e = P.queue[q];
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
 // of a hit next to each other and hits in queue order (one atomic per wave).
 __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 {
-    const unsigned int nHits = (unsigned int)P.queueCounters[0];
+    const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const int lane = int(threadIdx.x) & 63;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                 }
                 const uint32_t total = __shfl(prefix, 63, 64);
                 unsigned long long base = 0;
-                if (lane == 63 && total) base = atomicAdd(&P.queueCounters[2], (unsigned long long)total);
+                if (lane == 63 && total) base = atomicAdd(&P.queueCounters[Q_SHADOW_ITEMS], (unsigned long long)total);
                 base = __shfl(base, 63, 64);
                 at = uint32_t(base) + prefix - need;
             }
@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
     Counts cnt;
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
-    const unsigned long long queued = P.queueCounters[PRIMARY ? 4 : 2];
+    const unsigned long long queued = P.queueCounters[PRIMARY ? Q_GAVE_UP : Q_SHADOW_ITEMS];
     const unsigned long long nPackets = (queued + STREAM_RAYS - 1) / STREAM_RAYS;
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
@@ -431,7 +431,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
         bool zeroClass = false; // some ray of the packet has a direction component in the zero class
         while (used + WAVE <= SLOTS) {
             if (pkNext == pkEnd) {
-                if (lane == 0) pkNext = atomicAdd(&P.queueCounters[PRIMARY ? 3 : 1], GRAB);
+                if (lane == 0) pkNext = atomicAdd(&P.queueCounters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], GRAB);
                 pkNext = __shfl(pkNext, 0, 64);
                 if (pkNext >= nPackets) {
                     pkEnd = pkNext;
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 if (hits) {
                     const int leader = __ffsll((long long)hits) - 1;
                     unsigned int base = 0;
-                    if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[0], (unsigned long long)__popcll(hits));
+                    if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(hits));
                     base = __shfl(base, leader, 64);
                     if (present && found) {
                         HitEntry e;
@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
 // (reference src/light.cpp:124-220 for a hit whose colour is Lo, src/render.cpp:64-67).
 __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
 {
-    const unsigned int nHits = (unsigned int)P.queueCounters[0];
+    const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
     const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
     for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
         const HitEntry e = P.queue[q];
@@ -927,7 +927,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
         P.sampleEnd = sEnd;
         P.logicalBlocks = tiles * uint32_t(sEnd - sBegin);
         if (split) {
-            if ((e = hipMemsetAsync(P.queueCounters, 0, 8 * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(P.queueCounters, 0, Q_COUNT * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
