@@ -300,8 +300,9 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // 64: all lanes work as long as 64 pairs exist, however differently long the individual rays' traversals
 // are, and control flow is wave-uniform.  Pairs whose node is a leaf go to a second pool; a step that tests
 // primitives runs when 64 of those have gathered (or nothing else is left), so box tests and primitive tests
-// never share a step.  Rays live in LDS too (a lane works for a different ray every step); a ray that has
-// been blocked gets a flag in its record, and its remaining pairs are dropped when popped.
+// never share a step.  A lane works for a different ray every step; ray i stays in the registers of lane i and
+// is fetched from there with lane permutes.  A ray that has been blocked gets a flag in LDS, and its remaining
+// pairs are dropped when popped.
 //
 // Stack bound.  The top k <= 64 entries are popped, the topmost by lane k-1, the one below it by lane k-2, and so
 // on; the children are pushed in lane order (those of lane 0 lowest).  By induction the tree levels of the
@@ -324,7 +325,7 @@ constexpr int STREAM_STAGE_STRIDE = 1024 + 16;            // bytes between the f
 __host__ __device__ constexpr int stream_stack_entries(int levels) { return STREAM_PER_LEVEL * (levels < 2 ? 1 : levels - 1); }
 __host__ __device__ constexpr size_t stream_lds_bytes(int stackEntriesInLds)
 {
-    return size_t(STREAM_RAYS) * (64 + 4) + 4 * STREAM_STAGE_STRIDE + size_t(STREAM_LEAF_CAP) * 4 + size_t(stackEntriesInLds) * 4;
+    return 4 * STREAM_STAGE_STRIDE + size_t(STREAM_RAYS) * 4 + size_t(STREAM_LEAF_CAP) * 4 + size_t(stackEntriesInLds) * 4;
 }
 constexpr uint32_t STREAM_MAX_WAVES = 256u * 32u; // every wave slot of the chip
 
@@ -397,16 +398,22 @@ __device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, f32x2 o
     right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR) && (tinR < 0 ? toutR : tinR) < FLT_MAX;
 }
 
+// value of `v` in lane `src` (any lane may ask for any lane's value; all lanes must be active)
+__device__ __forceinline__ float lane_value(uint32_t src, float v)
+{
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(v)));
+}
+
 template <bool COUNT, bool PRIMARY>
 __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
 {
-    // per ray: (ox oy oz ox) (oy oz ix iy) (iz ix iy iz) (dx dy dz flags), i = 1/d
+    // Ray i of the packet lives in the registers of lane i (origin, direction, reciprocal direction); a lane that
+    // works on a pair of ray i fetches them with lane permutes, which need no LDS space.  Only the ray's flag word
+    // (zero-direction classes, "blocked") is in LDS, because other lanes set it.
     extern __shared__ f32x4 streamLds[];
-    f32x4* rays = streamLds;
-    constexpr int RAY_SLOTS = STREAM_RAYS;
-    char* stage = reinterpret_cast<char*>(rays + RAY_SLOTS * 4);
-    uint32_t* workOf = reinterpret_cast<uint32_t*>(stage + 4 * STREAM_STAGE_STRIDE);
-    uint32_t* leafPool = workOf + RAY_SLOTS;
+    char* stage = reinterpret_cast<char*>(streamLds);
+    uint32_t* flagsOf = reinterpret_cast<uint32_t*>(stage + 4 * STREAM_STAGE_STRIDE);
+    uint32_t* leafPool = flagsOf + STREAM_RAYS;
     const PairStack pool { leafPool + STREAM_LEAF_CAP, P.pairSpill + size_t(blockIdx.x) * P.pairSpillEntries, uint32_t(P.pairStackLds) };
     const int lane = int(threadIdx.x);
     Counts cnt;
@@ -419,109 +426,68 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
-    // Packets of 64 consecutive queued queries come from a cursor; a wave whose packet left no ray behind the root
-    // gate takes another one before it starts streaming.
-    constexpr unsigned long long GRAB = 1ull;
-    constexpr uint32_t SLOTS = STREAM_RAYS;
-    unsigned long long pkNext = 0, pkEnd = 0;
-    bool exhausted = false;
-    while (!exhausted) {
-        uint32_t used = 0; // ray slots taken
-        uint32_t count = 0, leafCount = 0;
-        bool zeroClass = false; // some ray of the packet has a direction component in the zero class
-        while (used + WAVE <= SLOTS) {
-            if (pkNext == pkEnd) {
-                if (lane == 0) pkNext = atomicAdd(&P.queueCounters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], GRAB);
-                pkNext = __shfl(pkNext, 0, 64);
-                if (pkNext >= nPackets) {
-                    pkEnd = pkNext;
-                    exhausted = true;
-                    break;
-                }
-                pkEnd = pkNext + GRAB < nPackets ? pkNext + GRAB : nPackets;
-            }
-            const unsigned long long pk = pkNext++;
-            // ---- 64 queries; the ones that pass the root gate start as pairs (ray, root)
-            bool have = false;
-            uint32_t work = 0;
-            RayD r = make_ray(splat3(0.0f), splat3(1.0f));
-            bool traced = false;
+    // Packets of 64 consecutive queued queries come from a cursor.
+    while (true) {
+        unsigned long long pk = 0;
+        if (lane == 0) pk = atomicAdd(&P.queueCounters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
+        pk = __shfl(pk, 0, 64);
+        if (pk >= nPackets) break;
+        // ---- this lane's query; the ones that pass the root gate start as pairs (ray, root)
+        const unsigned long long qi = pk * STREAM_RAYS + uint32_t(lane);
+        const bool have = qi < queued;
+        uint32_t work = 0;
+        RayD r = make_ray(splat3(0.0f), splat3(1.0f));
+        bool traced = false;
+        if (have) {
             if (PRIMARY) {
-                // 64 camera rays that gave up in k_primary
-                const unsigned long long qi = pk * STREAM_RAYS + uint32_t(lane);
-                have = qi < queued;
-                if (have) {
-                    work = P.shadowQueue[qi];
-                    HitEntry e;
-                    e.work = work;
-                    Rng rng;
-                    size_t pix;
-                    int sidx;
-                    hit_ray(P, e, nPix, rng, r, pix, sidx);
-                }
+                // a camera ray that gave up in k_primary
+                work = P.shadowQueue[qi];
+                HitEntry e;
+                e.work = work;
+                Rng rng;
+                size_t pix;
+                int sidx;
+                hit_ray(P, e, nPix, rng, r, pix, sidx);
             } else {
-                const unsigned long long qi = pk * STREAM_RAYS + uint32_t(lane);
-                have = qi < queued;
-                if (have) {
-                    work = P.shadowQueue[qi];
-                    const HitEntry e = P.queue[work / perHit];
-                    const int j = int(work % perHit);
-                    Rng rng;
-                    RayD cam;
-                    size_t pix;
-                    int sidx;
-                    hit_ray(P, e, nPix, rng, cam, pix, sidx);
-                    // which light and which of its samples: the last light whose first shadow sample is <= j
-                    int li = 0;
-                    for (int i = 0; i < P.nLights; i++)
-                        if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
-                    const LightDev& L = P.lights[li];
-                    const int k = j - L.shadowBase;
-                    vec3 position, color;
-                    light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
-                    const float epsilon = 0.00001f;
-                    const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
-                    r = make_ray(origin, position - origin);
-                    cnt.shadow++;
-                }
+                work = P.shadowQueue[qi];
+                const HitEntry e = P.queue[work / perHit];
+                const int j = int(work % perHit);
+                Rng rng;
+                RayD cam;
+                size_t pix;
+                int sidx;
+                hit_ray(P, e, nPix, rng, cam, pix, sidx);
+                // which light and which of its samples: the last light whose first shadow sample is <= j
+                int li = 0;
+                for (int i = 0; i < P.nLights; i++)
+                    if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
+                const LightDev& L = P.lights[li];
+                const int k = j - L.shadowBase;
+                vec3 position, color;
+                light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                const float epsilon = 0.00001f;
+                const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
+                r = make_ray(origin, position - origin);
+                cnt.shadow++;
             }
-            if (have) {
-                float tRoot;
-                if (COUNT) cnt.box++;
-                // root gate against the query's own bound (…hierarchy.cpp:296-301)
-                traced = S.numPrims > 0 && box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < tBound;
-            }
-            // a query stopped at the root is answered here; the others take a ray slot each
-            if (have && !traced) {
-                if (PRIMARY) {
-                    const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
-                    float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
-                    out[0] = c.x;
-                    out[1] = c.y;
-                    out[2] = c.z;
-                } else {
-                    P.visibility[work] = 1;
-                }
-            }
-            const unsigned long long m = __ballot(traced);
-            if (traced) {
-                const uint32_t rid = used + lanes_below(m);
-                const uint32_t flags = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u);
-                f32x4* rec = rays + rid * 4;
-                rec[0] = f32x4 { r.o.x, r.o.y, r.o.z, r.o.x };
-                rec[1] = f32x4 { r.o.y, r.o.z, r.inv.x, r.inv.y };
-                rec[2] = f32x4 { r.inv.z, r.inv.x, r.inv.y, r.inv.z };
-                rec[3] = f32x4 { r.d.x, r.d.y, r.d.z, __uint_as_float(flags) };
-                workOf[rid] = work;
-                if (S.rootRef >= 0) pool.put(count + rid - used, (rid << STREAM_REF_BITS) | uint32_t(S.rootRef));
-                else leafPool[leafCount + rid - used] = (rid << STREAM_REF_BITS) | uint32_t(~S.rootRef);
-            }
-            zeroClass = zeroClass || __ballot(traced && (r.zx || r.zy || r.zz)) != 0;
-            const uint32_t n = uint32_t(__popcll(m));
-            if (S.rootRef >= 0) count += n;
-            else leafCount += n;
-            used += n;
+            float tRoot;
+            if (COUNT) cnt.box++;
+            // root gate against the query's own bound (…hierarchy.cpp:296-301)
+            traced = S.numPrims > 0 && box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < tBound;
         }
+        const uint32_t zeroBits = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u);
+        flagsOf[lane] = zeroBits;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(traced);
+        // some ray of the packet has a direction component in the zero class
+        const bool zeroClass = __builtin_amdgcn_ballot_w64(traced && zeroBits != 0u) != 0;
+        uint32_t count = 0, leafCount = 0;
+        if (traced) {
+            const uint32_t at = lanes_below(m);
+            if (S.rootRef >= 0) pool.put(at, (uint32_t(lane) << STREAM_REF_BITS) | uint32_t(S.rootRef));
+            else leafPool[at] = (uint32_t(lane) << STREAM_REF_BITS) | uint32_t(~S.rootRef);
+        }
+        if (S.rootRef >= 0) count = uint32_t(__popcll(m));
+        else leafCount = uint32_t(__popcll(m));
         lds_fence();
         // ---- the stream
         while (count | leafCount) {
@@ -537,12 +503,12 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 } else {
                     if (got) e = pool.get(count + uint32_t(lane));
                 }
-                // the ray's record is read before the node loads are issued so that both are in flight together (an LDS
-                // read placed after them would be made to wait for them)
+                // the ray's values are fetched before the node loads are issued so that both are in flight together
+                // (an LDS-class operation placed after them would be made to wait for them)
                 const uint32_t rid = e >> STREAM_REF_BITS;
-                const f32x4* rec = rays + rid * 4;
-                const f32x4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                const uint32_t flags = __float_as_uint(rec[3].w);
+                const uint32_t flags = flagsOf[rid];
+                const float ox = lane_value(rid, r.o.x), oy = lane_value(rid, r.o.y), oz = lane_value(rid, r.o.z);
+                const float ix = lane_value(rid, r.inv.x), iy = lane_value(rid, r.inv.y), iz = lane_value(rid, r.inv.z);
                 asm volatile("" ::: "memory");
                 stage_records(S.nodes, (e & STREAM_REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
                 bool vL = false, vR = false;
@@ -553,15 +519,15 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                     const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
                     if (COUNT) cnt.box += 2;
                     if (!zeroClass) {
-                        boxes_entered(a, b, c, r0.xy, r0.zw, r1.xy, r1.zw, r2.xy, r2.zw, vL, vR);
+                        boxes_entered(a, b, c, f32x2 { ox, oy }, f32x2 { oz, ox }, f32x2 { oy, oz }, f32x2 { ix, iy }, f32x2 { iz, ix }, f32x2 { iy, iz }, vL, vR);
                     } else {
-                        RayD r;
-                        r.o = make3(r0.x, r0.y, r0.z);
-                        r.inv = make3(r1.z, r1.w, r2.x);
-                        r.zx = flags & 1u; r.zy = flags & 2u; r.zz = flags & 4u;
+                        RayD q;
+                        q.o = make3(ox, oy, oz);
+                        q.inv = make3(ix, iy, iz);
+                        q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
                         float tL, tR;
-                        vL = box_entry(r, a.x, a.y, a.z, a.w, b.x, b.y, tL) && tL < FLT_MAX;
-                        vR = box_entry(r, b.z, b.w, c.x, c.y, c.z, c.w, tR) && tR < FLT_MAX;
+                        vL = box_entry(q, a.x, a.y, a.z, a.w, b.x, b.y, tL) && tL < FLT_MAX;
+                        vR = box_entry(q, b.z, b.w, c.x, c.y, c.z, c.w, tR) && tR < FLT_MAX;
                     }
                     refL = __float_as_int(refs.x);
                     refR = __float_as_int(refs.y);
@@ -593,15 +559,15 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 const bool got = uint32_t(lane) < k;
                 const uint32_t e = got ? leafPool[leafCount - 1u - uint32_t(lane)] : 0u;
                 leafCount -= k;
-                stage_records(S.prims, (e & STREAM_REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
                 const uint32_t rid = e >> STREAM_REF_BITS;
-                f32x4* rec = rays + rid * 4;
-                const f32x4 r0 = rec[0], r3 = rec[3];
+                const uint32_t flags = flagsOf[rid];
+                RayD q;
+                q.o = make3(lane_value(rid, r.o.x), lane_value(rid, r.o.y), lane_value(rid, r.o.z));
+                q.d = make3(lane_value(rid, r.d.x), lane_value(rid, r.d.y), lane_value(rid, r.d.z));
+                asm volatile("" ::: "memory");
+                stage_records(S.prims, (e & STREAM_REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
                 stage_wait();
-                if (got && !(__float_as_uint(r3.w) & RAY_BLOCKED)) {
-                    RayD r;
-                    r.o = make3(r0.x, r0.y, r0.z);
-                    r.d = make3(r3.x, r3.y, r3.z);
+                if (got && !(flags & RAY_BLOCKED)) {
                     int32_t slot = int32_t(e & STREAM_REF_MASK);
                     int32_t more;
                     bool first = true;
@@ -621,8 +587,8 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                         more = prim_more(p);
                         if (COUNT) cnt.tri++;
                         float t;
-                        if (triangle_hit(r, p, tBound, t)) {
-                            atomicOr(reinterpret_cast<uint32_t*>(rec + 3) + 3, RAY_BLOCKED);
+                        if (triangle_hit(q, p, tBound, t)) {
+                            atomicOr(flagsOf + rid, RAY_BLOCKED);
                             break;
                         }
                         slot++;
@@ -631,37 +597,33 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
             }
             __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
         }
-        for (uint32_t rid = uint32_t(lane); rid < ((used + 63u) & ~63u); rid += WAVE) {
-            const bool present = rid < used;
-            const f32x4 last = rays[(present ? rid : 0u) * 4 + 3];
-            const bool found = __float_as_uint(last.w) & RAY_BLOCKED;
-            const uint32_t work = workOf[present ? rid : 0u];
-            if (!PRIMARY) {
-                if (present) P.visibility[work] = found ? 0 : 1;
-            } else {
-                // a camera ray that met no primitive is final (sky or black); the others queue up for k_closest,
-                // the rays of a tile next to each other (one atomic per wave)
-                if (present && !found) {
-                    const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, make3(last.x, last.y, last.z)) : splat3(0.0f);
-                    float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
-                    out[0] = c.x;
-                    out[1] = c.y;
-                    out[2] = c.z;
-                }
-                const unsigned long long hits = __ballot(present && found);
-                if (hits) {
-                    const int leader = __ffsll((long long)hits) - 1;
-                    unsigned int base = 0;
-                    if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(hits));
-                    base = __shfl(base, leader, 64);
-                    if (present && found) {
-                        HitEntry e;
-                        e.work = work;
-                        e.t = 0.0f;
-                        e.slot = -1;
-                        e.pad = 0;
-                        P.queue[base + lanes_below(hits)] = e;
-                    }
+        // ---- answers
+        const bool found = flagsOf[lane] & RAY_BLOCKED;
+        if (!PRIMARY) {
+            if (have) P.visibility[work] = found ? 0 : 1;
+        } else {
+            // a camera ray that met no primitive is final (sky or black); the others queue up for k_closest (one
+            // atomic per wave)
+            if (have && !found) {
+                const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
+                float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
+                out[0] = c.x;
+                out[1] = c.y;
+                out[2] = c.z;
+            }
+            const unsigned long long hits = __builtin_amdgcn_ballot_w64(have && found);
+            if (hits) {
+                const int leader = __ffsll((long long)hits) - 1;
+                unsigned int base = 0;
+                if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(hits));
+                base = __shfl(base, leader, 64);
+                if (have && found) {
+                    HitEntry e;
+                    e.work = work;
+                    e.t = 0.0f;
+                    e.slot = -1;
+                    e.pad = 0;
+                    P.queue[base + lanes_below(hits)] = e;
                 }
             }
         }
