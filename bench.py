@@ -103,7 +103,11 @@ def main():
         if world == 1:
             render_rows(0, HEIGHT, local)
         else:
-            tiling.render_local(render_rows, rank, world, WIDTH, HEIGHT, local)
+            # this rank's interleaved row blocks in one call, laid out like tiling.local_buffer
+            _, st = lib.render_blocks(bvh, cam, lights, n_lights, feats, p, WIDTH, HEIGHT, tiling.ROW_BLOCK, rank, world,
+                                      out=local.data_ptr(), device_ptr=1, stream=stream)
+            for name, _ in rt.Stats._fields_:
+                setattr(total, name, getattr(total, name) + getattr(st, name))
         return total
 
     def step():
@@ -148,8 +152,7 @@ def main():
     my_pixels = WIDTH * sum(tiling.block_rows(b, HEIGHT)[1] - tiling.block_rows(b, HEIGHT)[0] for b in my_blocks)
     # The dominant kernel is the shadow pass, k_stream<COUNT=false, PRIMARY=false>.  Its algorithmic bytes per launch:
     # 28 B ray in + 16 B result out per shadow ray, 32 B per ray/box test and 36 B per ray/triangle test it performs.  Its launch
-    # duration comes from HIP events recorded on the launch stream around it inside rt_render.  With N > 1 a rank
-    # issues several rt_render calls per frame, the per-kernel split is not recorded, and the whole call is used.
+    # duration comes from HIP events recorded on the launch stream around it inside rt_render.
     all_bytes = algorithmic_bytes(cst, my_pixels)
     all_flops = algorithmic_flops(cst)
     have_split = shadow_ms > 0.0

@@ -217,6 +217,16 @@ rt_status rt_render(const rt_bvh* bvh, const rt_camera* camera, const rt_light* 
     const rt_features* features, const rt_params* params, int32_t width, int32_t height, int32_t row_begin,
     int32_t row_end, float* out_rgb, int32_t device_ptr, void* stream, rt_stats* stats);
 
+/* The same for an interleaved set of row blocks in ONE call: the frame's Screen rows (counted from the TOP)
+ * are cut into blocks of `row_block` rows; this call renders blocks first_block, first_block + block_stride,
+ * first_block + 2 * block_stride, ... and writes them one after the other into `out_rgb` (block i of the call
+ * at rows [i * row_block, ...), top-most row first; only the frame's last block can be shorter).  This is the
+ * reference's row parallelism (`#pragma omp parallel for` over y, src/render.cpp:86-89) with the rows dealt to
+ * GPUs instead of threads: rank r of n renders (row_block, r, n) and the blocks are gathered afterwards. */
+rt_status rt_render_blocks(const rt_bvh* bvh, const rt_camera* camera, const rt_light* lights, int32_t n_lights,
+    const rt_features* features, const rt_params* params, int32_t width, int32_t height, int32_t row_block,
+    int32_t first_block, int32_t block_stride, float* out_rgb, int32_t device_ptr, void* stream, rt_stats* stats);
+
 /* addBloom (src/bloom.cpp:88-114) on a full width x height float RGB frame, in place. */
 rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params* params, int32_t device_ptr, void* stream);
 

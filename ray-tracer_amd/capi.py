@@ -346,6 +346,8 @@ class Library:
         lib.rt_visibility_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int32, C.POINTER(Features), C.c_void_p]
         lib.rt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.POINTER(Features), C.POINTER(Params),
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
+        lib.rt_render_blocks.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.POINTER(Features), C.POINTER(Params),
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
         lib.rt_bloom.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.c_void_p]
         lib.rt_default_params.argtypes = [C.POINTER(Params)]
         lib.rt_default_params.restype = None
@@ -400,6 +402,22 @@ class Library:
             img, ptr = None, out
         self.check(self.lib.rt_render(bvh, C.byref(camera), lights, n_lights, C.byref(feats), C.byref(params), width, height,
                                       row_begin, row_end, ptr, device_ptr, stream, C.byref(stats)))
+        return img, stats
+
+    def render_blocks(self, bvh, camera, lights, n_lights, feats, params, width, height, row_block, first_block, block_stride,
+                      out=None, device_ptr=0, stream=None):
+        """Renders Screen-row blocks first_block, first_block + block_stride, ... of row_block rows each in one call;
+        returns (image [rows of those blocks, width, 3] f32, Stats) for host output."""
+        n_blocks = (height + row_block - 1) // row_block
+        rows = sum(min(height, (b + 1) * row_block) - b * row_block for b in range(first_block, n_blocks, block_stride))
+        stats = Stats()
+        if out is None:
+            img = np.zeros((rows, width, 3), np.float32)
+            ptr = img.ctypes.data
+        else:
+            img, ptr = None, out
+        self.check(self.lib.rt_render_blocks(bvh, C.byref(camera), lights, n_lights, C.byref(feats), C.byref(params), width, height,
+                                             row_block, first_block, block_stride, ptr, device_ptr, stream, C.byref(stats)))
         return img, stats
 
     def bloom(self, image, params):

@@ -446,20 +446,50 @@ rt_status rt_visibility_batch(const rt_bvh* cb, const rt_ray* rays, uint64_t n, 
     return RT_OK;
 }
 
+namespace {
+rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
+    const rt_params* params, int32_t width, int32_t height, int32_t rowsLocal, int32_t rowTop, int32_t rowBlock, int32_t blockStride,
+    float* outRgb, int32_t devicePtr, void* stream, rt_stats* stats);
+}
+
 rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
     const rt_params* params, int32_t width, int32_t height, int32_t rowBegin, int32_t rowEnd, float* outRgb, int32_t devicePtr, void* stream, rt_stats* stats)
 {
+    if (width <= 0 || height <= 0 || rowBegin < 0 || rowEnd > height || rowBegin > rowEnd) return fail(RT_ERR_INVALID, "rt_render: bad frame or row range");
+    const int32_t rows = rowEnd - rowBegin;
+    return render_rows(cb, camera, lights, nLights, features, params, width, height, rows, height - rowEnd, rows > 0 ? rows : 1, 1, outRgb, devicePtr, stream, stats);
+}
+
+rt_status rt_render_blocks(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
+    const rt_params* params, int32_t width, int32_t height, int32_t rowBlock, int32_t firstBlock, int32_t blockStride, float* outRgb, int32_t devicePtr,
+    void* stream, rt_stats* stats)
+{
+    if (width <= 0 || height <= 0 || rowBlock <= 0 || firstBlock < 0 || blockStride <= 0) return fail(RT_ERR_INVALID, "rt_render_blocks: bad frame or block layout");
+    // blocks firstBlock, firstBlock + blockStride, ... of rowBlock Screen rows each; only the frame's last block can be short
+    const int64_t nBlocks = (int64_t(height) + rowBlock - 1) / rowBlock;
+    int64_t rows = 0;
+    for (int64_t blk = firstBlock; blk < nBlocks; blk += blockStride) {
+        const int64_t top = blk * rowBlock, bottom = top + rowBlock < height ? top + rowBlock : height;
+        rows += bottom - top;
+    }
+    return render_rows(cb, camera, lights, nLights, features, params, width, height, int32_t(rows), firstBlock * rowBlock, rowBlock, blockStride, outRgb, devicePtr, stream, stats);
+}
+
+namespace {
+rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
+    const rt_params* params, int32_t width, int32_t height, int32_t rowsLocal, int32_t rowTop, int32_t rowBlock, int32_t blockStride,
+    float* outRgb, int32_t devicePtr, void* stream, rt_stats* stats)
+{
     rt_bvh* b = const_cast<rt_bvh*>(cb);
     if (!b || !camera || !features || !params || (nLights && !lights) || nLights < 0) return fail(RT_ERR_INVALID, "rt_render: null argument");
-    if (width <= 0 || height <= 0 || rowBegin < 0 || rowEnd > height || rowBegin > rowEnd) return fail(RT_ERR_INVALID, "rt_render: bad frame or row range");
-    if (rowEnd > rowBegin && !outRgb) return fail(RT_ERR_INVALID, "rt_render: null output");
+    if (rowsLocal > 0 && !outRgb) return fail(RT_ERR_INVALID, "rt_render: null output");
     if (int64_t(width) * int64_t(height) > (int64_t(1) << 30)) return fail(RT_ERR_LIMIT, "frame larger than 2^30 pixels");
     if (features->environment_mapping && (params->enabled_skybox || params->enabled_refl_map) && b->scene->host.skybox.size() != 6)
         return fail(RT_ERR_INVALID, "environment mapping requested but the scene has no skybox");
     rt_status st = check_limits(b, features, params);
     if (st != RT_OK) return st;
     if (stats) std::memset(stats, 0, sizeof *stats);
-    if (rowEnd == rowBegin) return RT_OK;
+    if (rowsLocal == 0) return RT_OK;
 
     std::lock_guard<std::mutex> guard(b->lock);
     {
@@ -468,7 +498,7 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     }
     RT_HIP(hipSetDevice(b->scene->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const size_t nPix = size_t(rowEnd - rowBegin) * size_t(width);
+    const size_t nPix = size_t(rowsLocal) * size_t(width);
 
     FrameParams P;
     std::memset(&P, 0, sizeof P);
@@ -476,8 +506,10 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     fill_camera(*camera, P);
     P.width = width;
     P.height = height;
-    P.rowBegin = rowBegin;
-    P.rowEnd = rowEnd;
+    P.rowsLocal = rowsLocal;
+    P.rowTop = rowTop;
+    P.rowBlock = rowBlock;
+    P.blockStride = blockStride;
     P.f = *features;
     P.p = *params;
     if (nLights > MAX_LIGHTS) return fail(RT_ERR_LIMIT, "at most " + std::to_string(int(MAX_LIGHTS)) + " lights per frame");
@@ -576,6 +608,7 @@ rt_status rt_render(const rt_bvh* cb, const rt_camera* camera, const rt_light* l
     }
     return RT_OK;
 }
+} // namespace
 
 rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params* params, int32_t devicePtr, void* stream)
 {

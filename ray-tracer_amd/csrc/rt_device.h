@@ -33,7 +33,11 @@ struct FrameParams {
     quat camQ;
     float camPos[3], camUp[3], camLeft[3];
     float halfW, halfH;
-    int32_t width, height, rowBegin, rowEnd;
+    int32_t width, height;
+    // The rows this call renders, as LOCAL rows 0..rowsLocal-1 in Screen order (top-most first): local row r is
+    // Screen row (counted from the top) rowTop + (r / rowBlock) * blockStride * rowBlock + r % rowBlock.  One range
+    // of rows is a single block; interleaved blocks (multi-GPU tiling) have blockStride = number of ranks.
+    int32_t rowsLocal, rowTop, rowBlock, blockStride;
     rt_features f;
     rt_params p;
     LightDev lights[MAX_LIGHTS]; // travels in the kernel argument block: read with scalar loads, no upload to order
@@ -72,7 +76,8 @@ enum {
     Q_SHADOW_ITEMS = 32,     // shadow work items queued
     Q_GAVE_UP_PACKETS = 48,  // packets of given-up camera rays handed out
     Q_GAVE_UP = 64,          // camera rays that gave up
-    Q_COUNT = 80
+    Q_PRIMARY_TAIL = 80,     // chunks of logical blocks handed out by k_primary
+    Q_COUNT = 96
 };
 
 struct Counts {
@@ -880,10 +885,17 @@ __device__ __forceinline__ void sample_camera_ray(const FrameParams& P, int x, i
     }
 }
 
+// y coordinate (counted from the bottom, as the camera and the random streams use it) of a local row
+__device__ __forceinline__ int local_row_y(const FrameParams& P, int localRow)
+{
+    const int block = localRow / P.rowBlock;
+    return P.height - 1 - (P.rowTop + block * P.blockStride * P.rowBlock + (localRow - block * P.rowBlock));
+}
+
 __device__ __forceinline__ float* sample_slot(const FrameParams& P, size_t pix, int sidx)
 {
     if (P.samplesPerPixel == 1) return P.out + pix * 3;
-    return P.samples + (size_t(sidx) * size_t(P.rowEnd - P.rowBegin) * size_t(P.width) + pix) * 3;
+    return P.samples + (size_t(sidx) * size_t(P.rowsLocal) * size_t(P.width) + pix) * 3;
 }
 
 } // namespace rt

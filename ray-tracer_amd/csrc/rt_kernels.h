@@ -8,7 +8,7 @@ namespace rt {
 
 enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_SHADOW_BOX, STAT_SHADOW_TRI, STAT_CULLED, STAT_COUNT };
 
-// Renders rows [P.rowBegin, P.rowEnd): the traversal/shading passes, then (more than one sample per pixel)
+// Renders the P.rowsLocal local rows of the call: the traversal/shading passes, then (more than one sample per pixel)
 // the resolve pass.  `afterPasses`, when not null, is recorded between the two.  `split`, when not null, points
 // to four events recorded after the primary, cull, shadow and shade kernels if the call runs as those three passes
 // in a single chunk; *splitRecorded says whether that happened.

@@ -9,6 +9,7 @@ namespace {
 constexpr int BLOCK = 256;  // threads per block of the batch / bloom / resolve kernels
 constexpr int WAVE = 64;    // the render kernels run one wave per block: an 8x8 pixel tile at one sample index
 constexpr int TILE = 8;
+constexpr uint32_t PRIMARY_CHUNK = 16; // logical blocks per cursor grab of k_primary
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -55,9 +56,10 @@ __device__ __forceinline__ LaneId lane_id(const FrameParams& P, uint32_t logical
     LaneId id;
     id.sidx = P.sampleBegin + int(logical % uint32_t(nS));
     id.x = (tile % tilesX) * TILE + (lane & 7);
-    id.y = P.rowBegin + (tile / tilesX) * TILE + (lane >> 3);
-    id.valid = id.x < P.width && id.y < P.rowEnd;
-    id.pix = size_t(P.rowEnd - 1 - id.y) * size_t(P.width) + size_t(id.x);
+    const int localRow = (tile / tilesX) * TILE + (lane >> 3);
+    id.valid = id.x < P.width && localRow < P.rowsLocal;
+    id.y = local_row_y(P, id.valid ? localRow : 0);
+    id.pix = size_t(localRow) * size_t(P.width) + size_t(id.x);
     return id;
 }
 
@@ -92,7 +94,7 @@ __device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e,
     sidx = P.sampleBegin + int(e.work / nPix);
     pix = size_t(e.work % nPix);
     const int x = int(pix % size_t(P.width));
-    const int y = P.rowEnd - 1 - int(pix / size_t(P.width));
+    const int y = local_row_y(P, int(pix / size_t(P.width)));
     vec3 o, d;
     sample_camera_ray(P, x, y, sidx, rng, o, d);
     r = make_ray(o, d);
@@ -117,8 +119,22 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
     const int lane = int(threadIdx.x);
-    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
-    for (uint32_t logical = blockIdx.x; logical < P.logicalBlocks; logical += gridDim.x) {
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
+    // Work order.  A wave takes a CHUNK of PRIMARY_CHUNK logical blocks per cursor grab (the grab has to wait for the
+    // wave's outstanding stores, so it must be rare), and the blocks of chunk c are c, c + n, c + 2n, ... (n = number
+    // of chunks): one block out of each of PRIMARY_CHUNK horizontal bands of the frame.  Every chunk therefore costs
+    // about the same — busy middle and empty margins alike — and the waves finish together.
+    const uint32_t nChunks = (P.logicalBlocks + PRIMARY_CHUNK - 1) / PRIMARY_CHUNK;
+    uint32_t chunk = 0, member = PRIMARY_CHUNK;
+    while (true) {
+        if (member == PRIMARY_CHUNK) {
+            if (lane == 0) chunk = uint32_t(atomicAdd(&P.queueCounters[Q_PRIMARY_TAIL], 1ull));
+            chunk = __builtin_amdgcn_readfirstlane(chunk);
+            if (chunk >= nChunks) break;
+            member = 0;
+        }
+        const uint32_t logical = chunk + (member++) * nChunks;
+        if (logical >= P.logicalBlocks) continue;
         const LaneId id = lane_id(P, logical);
         int slot = -1;
         float t = FLT_MAX;
@@ -175,7 +191,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
     const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
-    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     for (unsigned int q = blockIdx.x * WAVE + threadIdx.x; q < nHits; q += gridDim.x * WAVE) {
         HitEntry e = P.queue[q];
         if (e.slot >= 0) continue;
@@ -210,7 +226,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
 __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 {
     const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
-    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const int lane = int(threadIdx.x) & 63;
     const unsigned int rounded = (nHits + 63u) & ~63u; // whole waves stay in the loop together
@@ -421,7 +437,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const unsigned long long queued = P.queueCounters[PRIMARY ? Q_GAVE_UP : Q_SHADOW_ITEMS];
     const unsigned long long nPackets = (queued + STREAM_RAYS - 1) / STREAM_RAYS;
-    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
@@ -637,7 +653,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
 __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
 {
     const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
-    const uint32_t nPix = uint32_t(size_t(P.rowEnd - P.rowBegin) * size_t(P.width));
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
         const HitEntry e = P.queue[q];
         if (e.slot < 0) continue;
@@ -675,7 +691,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
 // the pixel's flag is set, else the centre ray alone (render.cpp:109-118).
 __global__ void __launch_bounds__(BLOCK) k_resolve(const FrameParams P)
 {
-    const size_t nPix = size_t(P.rowEnd - P.rowBegin) * size_t(P.width);
+    const size_t nPix = size_t(P.rowsLocal) * size_t(P.width);
     const size_t pix = size_t(blockIdx.x) * BLOCK + threadIdx.x;
     if (pix >= nPix) return;
     const int S = P.samplesPerPixel;
@@ -874,7 +890,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
 {
     if (splitRecorded) *splitRecorded = false;
     FrameParams P = Pin;
-    const int rows = P.rowEnd - P.rowBegin;
+    const int rows = P.rowsLocal;
     if (rows <= 0 || P.width <= 0) return hipSuccess;
     const uint32_t tiles = uint32_t((P.width + TILE - 1) / TILE) * uint32_t((rows + TILE - 1) / TILE);
     const size_t lds = stack_bytes(P, WAVE);
