@@ -221,7 +221,8 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
 // visibility bit can reach the pixel at all.  With shading on, the reference multiplies the bit with a Phong
 // term (src/light.cpp:141-143,175-178,209-212) that is exactly zero when dot(N, L) <= 0 (src/shading.cpp:14-38):
 // diffuse and specular both vanish, so `shade * lighted` adds zero whatever the shadow ray would have found.
-// Those samples get visibility 1 without a ray; the others are appended to the shadow work queue, the items
+// Those samples get no ray (and their visibility byte stays whatever it was: any finite value times the zero term is
+// the same zero); the others are appended to the shadow work queue, the items
 // of a hit next to each other and hits in queue order (one atomic per wave).
 __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 {
@@ -251,9 +252,11 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
         }
         const vec3 point = r.o + (r.d * t);
         const vec3 N = normalize(s.normal);
+        // pass 0 decides and counts this hit's shadow rays (the first 64 decisions are kept as a bit mask), pass 1
+        // writes them at the offset the wave reserved
         uint32_t need = 0;
+        unsigned long long wantedBits = 0;
         for (int pass = 0; pass < 2; pass++) {
-            // pass 0 counts this hit's shadow rays, pass 1 writes them at the offset the wave reserved
             uint32_t at = 0;
             if (pass == 1) {
                 uint32_t prefix = need; // inclusive scan over the wave
@@ -274,19 +277,20 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                     const int total = L.nA * L.nB;
                     const uint32_t per = light_draws_per_sample(L.type);
                     for (int k = 0; k < total; k++) {
+                        const int j = L.shadowBase + k;
                         bool wanted = true;
-                        if (P.f.shading) {
+                        if (pass == 1 && j < 64) {
+                            wanted = (wantedBits >> j) & 1ull;
+                        } else if (P.f.shading) {
                             vec3 position, color;
                             light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
                             wanted = dot(N, normalize(position - point)) > 0; // same expression as phong()
                         }
-                        const uint32_t item = q * perHit + uint32_t(L.shadowBase + k);
+                        const uint32_t item = q * perHit + uint32_t(j);
                         if (pass == 0) {
                             need += wanted ? 1u : 0u;
-                            if (!wanted) {
-                                P.visibility[item] = 1;
-                                culled++;
-                            }
+                            if (wanted && j < 64) wantedBits |= 1ull << j;
+                            if (!wanted) culled++; // its visibility byte is never written: k_shade multiplies it with exact zeros
                         } else if (wanted) {
                             P.shadowQueue[at++] = item;
                         }
