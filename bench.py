@@ -241,13 +241,13 @@ def measured_traffic(world):
 
 def cpu_baseline(rt, scene, cam, feats, params):
     """The oracle (oracle/cpu_ref.cpp, the CPU restatement of the reference's algorithm) timed on this
-    machine's host cores on every 24th row of the same frame at full sample count."""
+    machine's host cores on every 12th row of the same frame at full sample count."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as o
 
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     osc = o.OracleScene(scene)
-    row_step = 24
+    row_step = 12
     t0 = time.perf_counter()
     _, st = osc.render(cam, feats, params, WIDTH, HEIGHT, row_step=row_step, threads=threads)
     dt = time.perf_counter() - t0
