@@ -64,9 +64,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a box with a single GPU: every rank uses GPU 0 and the exchange runs on gloo
+    rehearsal = os.environ.get("BENCH_ONE_GPU_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -88,7 +95,8 @@ def main():
     # interleaved 16-row blocks, block b belongs to rank b % world (ray-tracer_amd/tiling.py)
     my_blocks = tiling.blocks_of_rank(rank, world, HEIGHT)
     local = tiling.local_buffer(world, WIDTH, HEIGHT, dev)
-    gathered = [torch.empty_like(local) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = tiling.gather_buffers(local, world) if (world > 1 and rank == 0) else None
+    row_index = tiling.frame_row_index(world, HEIGHT, dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def render_frame(p):
@@ -113,7 +121,7 @@ def main():
     def step():
         st = render_frame(params)
         if world > 1:
-            tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered)
+            tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered, row_index=row_index)
         return st
 
     def barrier():

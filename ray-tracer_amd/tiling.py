@@ -46,20 +46,44 @@ def render_local(render_rows, rank, world, width, height, local, block=ROW_BLOCK
     return results
 
 
-def gather_frame(local, rank, world, width, height, block=ROW_BLOCK, gathered=None):
+def gather_buffers(local, world):
+    """Receive buffers for gather_frame that can be kept across frames: one tensor holding every rank's tile store
+    (so that the frame can be put together with a single row gather) and the per-rank views torch.distributed
+    wants."""
+    store = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    return store, [store[r] for r in range(world)]
+
+
+def frame_row_index(world, height, device, block=ROW_BLOCK):
+    """For every Screen row of the frame, its row in the stacked tile stores [world * rows_per_rank]."""
+    per_rank = blocks_per_rank(world, height, block) * block
+    idx = torch.empty(height, dtype=torch.long)
+    for r in range(world):
+        for k, b in enumerate(blocks_of_rank(r, world, height, block)):
+            top, bottom, _, _ = block_rows(b, height, block)
+            idx[top:bottom] = torch.arange(r * per_rank + k * block, r * per_rank + k * block + (bottom - top))
+    return idx.to(device)
+
+
+def gather_frame(local, rank, world, width, height, block=ROW_BLOCK, gathered=None, row_index=None):
     """Gathers every rank's tile store on rank 0 and returns the assembled [height, width, 3] frame there
-    (None elsewhere).  `gathered` may carry preallocated receive buffers across frames."""
+    (None elsewhere).  `gathered` (from gather_buffers) and `row_index` (from frame_row_index) may be kept across
+    frames; with both, putting the frame together is one row gather on the device."""
     if world == 1:
         return local[:height]
     if rank == 0 and gathered is None:
-        gathered = [torch.empty_like(local) for _ in range(world)]
-    dist.gather(local, gathered if rank == 0 else None, dst=0)
+        gathered = gather_buffers(local, world)
+    dist.gather(local, gathered[1] if rank == 0 else None, dst=0)
     if rank != 0:
         return None
-    return assemble(gathered, world, width, height, block)
+    if row_index is None:
+        row_index = frame_row_index(world, height, local.device, block)
+    store = gathered[0]
+    return store.view(world * store.shape[1], width, 3).index_select(0, row_index)
 
 
 def assemble(gathered, world, width, height, block=ROW_BLOCK):
+    """Reference form of the assembly, block by block (tests compare gather_frame against it)."""
     frame = torch.empty((height, width, 3), dtype=gathered[0].dtype, device=gathered[0].device)
     for r in range(world):
         for k, b in enumerate(blocks_of_rank(r, world, height, block)):

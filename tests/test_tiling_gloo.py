@@ -66,6 +66,17 @@ def test_tiles_gather_to_the_single_process_frame(tmp_path, world):
     assert int(np.load(out + ".rays.npy")[0]) == stats.total_rays()
 
 
+def test_row_gather_equals_blockwise_assembly():
+    for world, H in ((2, 56), (3, 100), (8, 1080)):
+        W = 5
+        per = tiling.blocks_per_rank(world, H) * tiling.ROW_BLOCK
+        stores = [torch.arange(per * W * 3, dtype=torch.float32).reshape(per, W, 3) + 1e6 * r for r in range(world)]
+        ref = tiling.assemble(stores, world, W, H)
+        idx = tiling.frame_row_index(world, H, "cpu")
+        got = torch.stack(stores).view(world * per, W, 3).index_select(0, idx)
+        assert torch.equal(got, ref)
+
+
 def test_block_bookkeeping():
     for world in (1, 2, 4, 8):
         seen = []
