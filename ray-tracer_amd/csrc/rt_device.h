@@ -62,6 +62,7 @@ struct FrameParams {
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
     int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features
     uint32_t logicalBlocks;      // (tile, sample) blocks of the current pass
+    uint32_t primaryChunk;       // logical blocks a wave of k_primary takes per cursor grab
     int32_t pairStackLds;        // shadow pass: entries of a wave's pair stack kept in LDS; the rest of the bound spills
     uint32_t* pairSpill;         // [pairSpillWaves][pairSpillEntries] spill area of the pair stacks
     uint32_t pairSpillEntries;
@@ -76,8 +77,8 @@ enum {
     Q_SHADOW_ITEMS = 32,     // shadow work items queued
     Q_GAVE_UP_PACKETS = 48,  // packets of given-up camera rays handed out
     Q_GAVE_UP = 64,          // camera rays that gave up
-    Q_PRIMARY_TAIL = 80,     // chunks of logical blocks handed out by k_primary
-    Q_COUNT = 96
+    Q_PRIMARY_CURSORS = 80,  // 16 cursors (one per 128-byte line) that hand out k_primary's chunks of logical blocks
+    Q_COUNT = 80 + 16 * 16
 };
 
 struct Counts {

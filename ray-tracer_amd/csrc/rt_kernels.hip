@@ -9,7 +9,8 @@ namespace {
 constexpr int BLOCK = 256;  // threads per block of the batch / bloom / resolve kernels
 constexpr int WAVE = 64;    // the render kernels run one wave per block: an 8x8 pixel tile at one sample index
 constexpr int TILE = 8;
-constexpr uint32_t PRIMARY_CHUNK = 16; // logical blocks per cursor grab of k_primary
+constexpr uint32_t PRIMARY_CURSORS = 16;  // cursors that hand out k_primary's chunks
+constexpr uint32_t PRIMARY_CHUNK_MAX = 16; // logical blocks per cursor grab of k_primary when the pass is large
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -120,17 +121,35 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
     Counts cnt;
     const int lane = int(threadIdx.x);
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
-    // Work order.  A wave takes a CHUNK of PRIMARY_CHUNK logical blocks per cursor grab (the grab has to wait for the
-    // wave's outstanding stores, so it must be rare), and the blocks of chunk c are c, c + n, c + 2n, ... (n = number
-    // of chunks): one block out of each of PRIMARY_CHUNK horizontal bands of the frame.  Every chunk therefore costs
+    // Work order.  A wave takes a CHUNK of P.primaryChunk logical blocks per cursor grab (the grab has to wait for the
+    // wave's outstanding stores, so it must be rare when there is much to do), and the blocks of chunk c are c, c + n,
+    // c + 2n, ... (n = number of chunks): one block out of each of that many horizontal bands of the frame.  Every chunk therefore costs
     // about the same — busy middle and empty margins alike — and the waves finish together.
-    const uint32_t nChunks = (P.logicalBlocks + PRIMARY_CHUNK - 1) / PRIMARY_CHUNK;
-    uint32_t chunk = 0, member = PRIMARY_CHUNK;
+    // The chunks are handed out by PRIMARY_CURSORS cursors, each over its own slice of the chunk numbers and in a
+    // cache line of its own (atomics on one address are served one after the other, about 10 ns each: a single
+    // cursor would cap the kernel at its number of grabs times that).  A wave starts at the cursor of its block
+    // number and moves on to the next one when a slice is used up.
+    const uint32_t chunkBlocks = P.primaryChunk;
+    const uint32_t nChunks = (P.logicalBlocks + chunkBlocks - 1) / chunkBlocks;
+    const uint32_t perCursor = (nChunks + PRIMARY_CURSORS - 1) / PRIMARY_CURSORS;
+    uint32_t cursor = blockIdx.x % PRIMARY_CURSORS, cursorsTried = 0;
+    uint32_t chunk = 0, member = chunkBlocks;
     while (true) {
-        if (member == PRIMARY_CHUNK) {
-            if (lane == 0) chunk = uint32_t(atomicAdd(&P.queueCounters[Q_PRIMARY_TAIL], 1ull));
-            chunk = __builtin_amdgcn_readfirstlane(chunk);
-            if (chunk >= nChunks) break;
+        if (member == chunkBlocks) {
+            bool gotChunk = false;
+            while (cursorsTried < PRIMARY_CURSORS) {
+                uint32_t i = 0;
+                if (lane == 0) i = uint32_t(atomicAdd(&P.queueCounters[Q_PRIMARY_CURSORS + cursor * 16u], 1ull));
+                i = __builtin_amdgcn_readfirstlane(i);
+                chunk = cursor * perCursor + i;
+                if (i < perCursor && chunk < nChunks) {
+                    gotChunk = true;
+                    break;
+                }
+                cursor = (cursor + 1u) % PRIMARY_CURSORS;
+                cursorsTried++;
+            }
+            if (!gotChunk) break;
             member = 0;
         }
         const uint32_t logical = chunk + (member++) * nChunks;
@@ -440,7 +459,10 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const unsigned long long queued = P.queueCounters[PRIMARY ? Q_GAVE_UP : Q_SHADOW_ITEMS];
-    const unsigned long long nPackets = (queued + STREAM_RAYS - 1) / STREAM_RAYS;
+    // camera rays that gave up are long by construction: a quarter of the slots gives the stream enough pairs, and four
+    // times as many waves share the (often few) rays
+    const uint32_t raysPerPacket = PRIMARY ? STREAM_RAYS / 4 : STREAM_RAYS;
+    const unsigned long long nPackets = (queued + raysPerPacket - 1) / raysPerPacket;
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
     const lds_bytes stageLds = (lds_bytes)stage;
@@ -453,8 +475,8 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
         pk = __shfl(pk, 0, 64);
         if (pk >= nPackets) break;
         // ---- this lane's query; the ones that pass the root gate start as pairs (ray, root)
-        const unsigned long long qi = pk * STREAM_RAYS + uint32_t(lane);
-        const bool have = qi < queued;
+        const unsigned long long qi = pk * raysPerPacket + uint32_t(lane);
+        const bool have = uint32_t(lane) < raysPerPacket && qi < queued;
         uint32_t work = 0;
         RayD r = make_ray(splat3(0.0f), splat3(1.0f));
         bool traced = false;
@@ -843,8 +865,16 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
 {
     const size_t streamLds = stream_lds_bytes(P.pairStackLds);
     {
-        if (P.countTests) launch_walkers(k_primary<PRUNE, true>, P, lds, stream);
-        else launch_walkers(k_primary<PRUNE, false>, P, lds, stream);
+        {
+            // enough chunks for every resident wave to come back to the cursor several times
+            const uint32_t waves = P.countTests ? resident_blocks(k_primary<PRUNE, true>, WAVE, lds) : resident_blocks(k_primary<PRUNE, false>, WAVE, lds);
+            uint32_t chunk = P.logicalBlocks / (waves * 8u);
+            chunk = chunk < 1u ? 1u : (chunk > PRIMARY_CHUNK_MAX ? PRIMARY_CHUNK_MAX : chunk);
+            FrameParams Q = P;
+            Q.primaryChunk = chunk;
+            if (Q.countTests) launch_walkers(k_primary<PRUNE, true>, Q, lds, stream);
+            else launch_walkers(k_primary<PRUNE, false>, Q, lds, stream);
+        }
         // how many rays gave up, and how many of those meet a primitive, is only known on the device: both kernels
         // get a grid that covers every resident wave
         uint32_t cap = P.countTests ? resident_blocks(k_stream<true, true>, WAVE, streamLds) : resident_blocks(k_stream<false, true>, WAVE, streamLds);
