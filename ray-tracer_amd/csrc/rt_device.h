@@ -52,7 +52,7 @@ struct FrameParams {
     int32_t sampleBegin, sampleEnd, samplesPerPixel;
     unsigned long long* stats; // primary, shadow, bounce, probe, box, tri, overflow
     int32_t countTests;
-    // two-kernel path: queue of primary hits, [0] = entries written, [1] = entries handed out
+    // queue passes (direct-lighting frames): the hits of the camera rays, one entry each
     struct HitEntry* queue;
     unsigned long long* queueCounters; // Q_COUNT counters of the current pass, see below
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
@@ -73,7 +73,7 @@ struct FrameParams {
 // other, and the kernels of a pass hammer different counters at the same time.
 enum {
     Q_HITS = 0,              // hit-queue entries
-    Q_SHADOW_PACKETS = 16,   // shadow packets handed out
+    Q_SHADOW_PACKETS = 16,   // packets of shadow work items handed out
     Q_SHADOW_ITEMS = 32,     // shadow work items queued
     Q_GAVE_UP_PACKETS = 48,  // packets of given-up camera rays handed out
     Q_GAVE_UP = 64,          // camera rays that gave up
@@ -850,11 +850,13 @@ __device__ vec3 render_sample(const FrameParams& P, int x, int y, int sidx, Stac
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Two-kernel form of the same per-sample evaluation, used when a sample is one camera ray plus direct
-// lighting (no mirror / glossy / transparency / reflection-map / depth-of-field branch can trigger):
-//   primary pass: camera ray -> closest hit; misses are finished on the spot, hits are queued;
-//   direct pass : one lane per queued hit -> surface attributes, light samples, shadow rays, Phong.
-// Queueing the hits compacts them, so the second pass runs with full waves and fewer live registers.
+// Queue form of the same per-sample evaluation, used when a sample is one camera ray plus direct lighting (no
+// mirror / glossy / transparency / reflection-map / depth-of-field branch can trigger).  Passes (rt_kernels.hip):
+//   primary: camera ray -> closest hit; misses are finished on the spot, hits are queued (compacted: the later
+//            passes run on full waves);
+//   cull   : which light samples of a hit need a shadow ray at all;
+//   shadow : the visibility bit of each of those;
+//   shade  : one lane per queued hit -> surface attributes, light samples, Phong x visibility.
 // ---------------------------------------------------------------------------------------------------
 struct HitEntry {
     uint32_t work; // sample * pixelsInSlice + pixel (pixel = Screen-order index inside the rendered row slice)
