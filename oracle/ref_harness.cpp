@@ -773,6 +773,29 @@ static std::vector<glm::vec3> light_sample_positions(const Scene& scene)
 
 int main(int argc, char** argv)
 {
+    if (argc == 5 && std::string(argv[1]) == "--obj") {
+        // ref_dump --obj <file.obj> <0|1: centre and normalise> <output prefix>: the reference's loadMesh on any OBJ
+        // file (used to pin the facade's own loader on OBJ files written for this repository's tests)
+        std::vector<Mesh> meshes = loadMesh(argv[2], std::atoi(argv[3]) != 0);
+        std::vector<float> verts, materials;
+        std::vector<uint32_t> tris;
+        std::vector<int32_t> meshTable; // vtxOff, vtxCnt, triOff, triCnt, has texture
+        for (const Mesh& m : meshes) {
+            meshTable.insert(meshTable.end(), { int32_t(verts.size() / 8), int32_t(m.vertices.size()), int32_t(tris.size() / 3), int32_t(m.triangles.size()), m.material.kdTexture ? 1 : 0 });
+            for (const Vertex& v : m.vertices)
+                verts.insert(verts.end(), { v.position.x, v.position.y, v.position.z, v.normal.x, v.normal.y, v.normal.z, v.texCoord.x, v.texCoord.y });
+            for (const glm::uvec3& t : m.triangles)
+                tris.insert(tris.end(), { t.x, t.y, t.z });
+            materials.insert(materials.end(), { m.material.kd.x, m.material.kd.y, m.material.kd.z, m.material.ks.x, m.material.ks.y, m.material.ks.z, m.material.shininess, m.material.transparency });
+        }
+        g_out = "";
+        const std::string prefix = argv[4];
+        npy_f32(prefix + "vertices", { verts.size() / 8, 8 }, verts.data());
+        npy_u32(prefix + "triangles", { tris.size() / 3, 3 }, tris.data());
+        npy_i32(prefix + "mesh_table", { meshTable.size() / 5, 5 }, meshTable.data());
+        npy_f32(prefix + "materials", { materials.size() / 8, 8 }, materials.data());
+        return 0;
+    }
     if (argc < 2) { std::fprintf(stderr, "usage: ref_dump <outdir> [data dir]\n"); return 2; }
     g_out = argv[1];
     std::filesystem::create_directories(g_out);

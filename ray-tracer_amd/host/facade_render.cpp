@@ -2,6 +2,8 @@
 // BvhInterface + renderRayTracing exactly the way the reference's CLI mode does (src/main.cpp:523-545), and
 // writes the float frame (and optionally a BMP).
 //   facade_render <scene.rtscene> <out.f32> <width> <height> <feature flags, comma separated> [out.bmp]
+// Second form, no rendering: reads a Wavefront OBJ file with loadMesh and writes the meshes as a binary scene.
+//   facade_render --obj <file.obj> <0|1: centre and normalise> <out.rtscene>
 #include "rt_facade.h"
 
 #include <cstdio>
@@ -12,8 +14,35 @@
 
 using namespace rtamd;
 
+static int convert_obj(const char* objFile, bool normalize, const char* outFile)
+{
+    std::vector<Mesh> meshes;
+    try {
+        meshes = loadMesh(objFile, normalize);
+    } catch (const std::exception&) {
+        return 1;
+    }
+    std::ofstream out(outFile, std::ios::binary);
+    out.write("RTSCENE1", 8);
+    const uint32_t counts[8] = { uint32_t(meshes.size()), 0, 0, 0, 0, 0, 0, 0 };
+    out.write(reinterpret_cast<const char*>(counts), sizeof counts);
+    for (const Mesh& m : meshes) {
+        const uint32_t n[2] = { uint32_t(m.vertices.size()), uint32_t(m.triangles.size()) };
+        out.write(reinterpret_cast<const char*>(n), sizeof n);
+        const float mat[8] = { m.material.kd.x, m.material.kd.y, m.material.kd.z, m.material.ks.x, m.material.ks.y, m.material.ks.z, m.material.shininess, m.material.transparency };
+        out.write(reinterpret_cast<const char*>(mat), sizeof mat);
+        const int32_t texture = m.material.kdTextureFile.empty() ? -1 : 0;
+        out.write(reinterpret_cast<const char*>(&texture), sizeof texture);
+        out.write(reinterpret_cast<const char*>(m.vertices.data()), std::streamsize(m.vertices.size() * sizeof(Vertex)));
+        out.write(reinterpret_cast<const char*>(m.triangles.data()), std::streamsize(m.triangles.size() * sizeof(uvec3)));
+    }
+    std::printf("meshes %zu\n", meshes.size());
+    return out ? 0 : 1;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 5 && std::strcmp(argv[1], "--obj") == 0) return convert_obj(argv[2], std::atoi(argv[3]) != 0, argv[4]);
     if (argc < 6) {
         std::fprintf(stderr, "usage: facade_render scene out.f32 W H flags [out.bmp]\n");
         return 2;

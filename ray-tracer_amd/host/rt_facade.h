@@ -60,6 +60,7 @@ struct Material {
     float shininess { 1.0f };
     float transparency { 1.0f };
     std::shared_ptr<Image> kdTexture;
+    std::string kdTextureFile; // no counterpart: map_Kd file name as loadMesh read it (this library decodes no image files)
 };
 struct Mesh {
     std::vector<Vertex> vertices;
@@ -198,6 +199,13 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
 
 // Last rt_stats of renderRayTracing on this thread (no counterpart; the reference only prints wall time).
 const rt_stats& lastRenderStats();
+
+// Wavefront OBJ (+ MTL) file -> one Mesh per material run, as the reference's loadMesh does it (reference
+// framework/src/mesh.cpp:52-149 on tinyobjloader 2.0.0): same vertices in the same order, same triangles, same
+// materials; centerAndNormalize applies the reference's centring and scaling to the unit sphere (:151-176).
+// Texture files are not decoded: Material::kdTextureFile carries the name, kdTexture stays empty.  Throws
+// std::exception like the reference when the file is missing or malformed.
+std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNormalize = false);
 
 // Flat binary scene file written by tests (meshes, materials, textures, spheres, lights, skybox); an extension
 // used where the reference would call loadScenePrebuilt with its OBJ files.

@@ -1,0 +1,92 @@
+"""The facade's OBJ/MTL loader (ray-tracer_amd/host/obj_loader.cpp) against the reference's loadMesh:
+  - on OBJ files written for this repository (tests/golden/obj_own/), expected arrays from the compiled reference
+    (oracle/gen_obj_golden.py -> tests/golden/obj_own.npz);
+  - on the reference's own data files, when its checkout is present on this machine, against the scene arrays
+    of the golden fixtures (which the reference's loader produced).
+Bit-exact: vertices (position, normal, texture coordinate) in the same order, triangles, mesh split, materials."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+
+DRIVER = os.path.join(o.ROOT, "ray-tracer_amd", "host", "facade_render")
+OWN = os.path.join(o.ROOT, "tests", "golden", "obj_own")
+REFERENCE_DATA = "/root/reference/data"
+
+
+def load_with_facade(tmp_path, obj_file, normalize):
+    out = str(tmp_path / "meshes.rtscene")
+    res = subprocess.run([DRIVER, "--obj", obj_file, str(int(normalize)), out], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    b = open(out, "rb").read()
+    assert b[:8] == b"RTSCENE1"
+    n = struct.unpack_from("<8I", b, 8)[0]
+    off = 40
+    verts, tris, table, mats = [], [], [], []
+    vo = to = 0
+    for _ in range(n):
+        nv, nt = struct.unpack_from("<II", b, off)
+        off += 8
+        mats.append(np.frombuffer(b, "<f4", 8, off))
+        off += 32
+        tex = struct.unpack_from("<i", b, off)[0]
+        off += 4
+        verts.append(np.frombuffer(b, "<f4", nv * 8, off).reshape(nv, 8))
+        off += nv * 32
+        tris.append(np.frombuffer(b, "<u4", nt * 3, off).reshape(nt, 3))
+        off += nt * 12
+        table.append([vo, nv, to, nt, 1 if tex >= 0 else 0])
+        vo += nv
+        to += nt
+    return np.concatenate(verts), np.concatenate(tris), np.array(table, np.int32), np.array(mats, np.float32)
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("normalize", [0, 1])
+def test_own_obj_files_load_like_the_reference(tmp_path, normalize):
+    g = np.load(os.path.join(o.ROOT, "tests", "golden", "obj_own.npz"))
+    for name in sorted(f for f in os.listdir(OWN) if f.endswith(".obj")):
+        v, t, table, m = load_with_facade(tmp_path, os.path.join(OWN, name), normalize)
+        key = f"{name}.{normalize}."
+        assert np.array_equal(table, g[key + "mesh_table"])
+        assert np.array_equal(t, g[key + "triangles"])
+        assert same_bits(v, g[key + "vertices"])
+        assert same_bits(m, g[key + "materials"])
+
+
+def test_missing_and_unsupported_files_fail_like_the_reference(tmp_path):
+    res = subprocess.run([DRIVER, "--obj", str(tmp_path / "nothing.obj"), "0", str(tmp_path / "x")], capture_output=True, text=True)
+    assert res.returncode != 0 and "does not exist" in res.stderr
+    pentagon = tmp_path / "pentagon.obj"
+    pentagon.write_text("v 0 0 0\nv 1 0 0\nv 2 1 0\nv 1 2 0\nv 0 1 0\nf 1 2 3 4 5\n")
+    res = subprocess.run([DRIVER, "--obj", str(pentagon), "0", str(tmp_path / "x")], capture_output=True, text=True)
+    assert res.returncode != 0 and "more than four corners" in res.stderr
+
+
+# scene of the golden fixtures -> (file in the reference's data directory, centre and normalise) (reference src/scene.cpp:10-106)
+REFERENCE_SCENES = {
+    "single_triangle": ("triangle.obj", 0), "cube_segment": ("cube.obj", 0), "cube_textured": ("cube-textured.obj", 0),
+    "cornell": ("CornellBox-Mirror-Rotated.obj", 1), "cornell_para": ("CornellBox-Mirror-Rotated.obj", 1), "monkey": ("monkey.obj", 1),
+    "teapot": ("teapot.obj", 1), "quad_textured": ("quadtextured.obj", 1), "transparent_cubes": ("transparent-cubes.obj", 1),
+    "transparent_cornell": ("cornelltransparent.obj", 1),
+}
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE_DATA), reason="the reference checkout (and with it its data files) is not on this machine")
+@pytest.mark.parametrize("scene", sorted(REFERENCE_SCENES))
+def test_reference_data_files_give_the_golden_scenes(tmp_path, scene):
+    obj, normalize = REFERENCE_SCENES[scene]
+    g = o.golden(scene)
+    v, t, table, m = load_with_facade(tmp_path, os.path.join(REFERENCE_DATA, obj), normalize)
+    assert np.array_equal(table[:, :4], g["scene.mesh_table"][:, :4])
+    assert np.array_equal(table[:, 4] > 0, g["scene.mesh_table"][:, 4] >= 0)  # which meshes carry a texture
+    assert np.array_equal(t, g["scene.triangles"])
+    assert same_bits(v, g["scene.vertices"])
+    assert same_bits(m, g["scene.materials"])
