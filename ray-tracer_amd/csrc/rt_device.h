@@ -862,7 +862,7 @@ struct HitEntry {
     uint32_t work; // sample * pixelsInSlice + pixel (pixel = Screen-order index inside the rendered row slice)
     float t;
     int32_t slot;
-    uint32_t pad;
+    uint32_t pad; // 1 once k_cull has written the hit's colour (no light sample reaches it)
 };
 
 __device__ __forceinline__ void sample_camera_ray(const FrameParams& P, int x, int y, int sidx, Rng& rng, vec3& o, vec3& d)

@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     const int lane = int(threadIdx.x) & 63;
     const unsigned int rounded = (nHits + 63u) & ~63u; // whole waves stay in the loop together
     uint32_t culled = 0;
+    bool everyLightShadowed = true;
+    for (int li = 0; li < P.nLights; li++)
+        if (light_enabled(P, P.lights[li].type) && P.lights[li].shadowBase < 0) everyLightShadowed = false;
     for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < rounded; q += gridDim.x * BLOCK) {
         bool live = q < nHits;
         Rng rng;
@@ -316,6 +319,16 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                     }
                 }
             }
+        }
+        // A hit none of whose light samples is wanted, in a frame where every enabled light casts shadows, sums exact
+        // zeros (+0 + -0 = +0): its colour is written here and k_shade skips it.
+        if (live && need == 0 && P.f.shading && everyLightShadowed) {
+            const HitEntry e = P.queue[q];
+            float* out = sample_slot(P, size_t(e.work % nPix), P.sampleBegin + int(e.work / nPix));
+            out[0] = 0.0f;
+            out[1] = 0.0f;
+            out[2] = 0.0f;
+            P.queue[q].pad = 1;
         }
     }
     if (P.stats) {
@@ -682,7 +695,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
         const HitEntry e = P.queue[q];
-        if (e.slot < 0) continue;
+        if (e.slot < 0 || e.pad != 0) continue; // nothing found after all / colour already written by k_cull
         Rng rng;
         RayD r;
         size_t pix;
