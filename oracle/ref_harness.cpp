@@ -796,6 +796,24 @@ int main(int argc, char** argv)
         npy_f32(prefix + "materials", { materials.size() / 8, 8 }, materials.data());
         return 0;
     }
+    if (argc == 4 && std::string(argv[1]) == "--image") {
+        // ref_dump --image <file> <out.npy>: the reference's Image(path) (stb_image, three channels) as height x width x 3
+        // bytes; exit status 3 when the reference throws (missing or undecodable file)
+        try {
+            Image img(argv[2]);
+            std::vector<uint8_t> bytes;
+            bytes.reserve(img.pixels.size() * 3);
+            for (const glm::vec3& p : img.pixels)
+                for (int c = 0; c < 3; c++) bytes.push_back(uint8_t(std::lround(p[c] * 255.0f)));
+            g_out = "";
+            std::string out = argv[3];
+            if (out.size() > 4 && out.substr(out.size() - 4) == ".npy") out.resize(out.size() - 4);
+            npy_u8(out, { size_t(img.height), size_t(img.width), 3 }, bytes.data());
+        } catch (const std::exception&) {
+            return 3;
+        }
+        return 0;
+    }
     if (argc < 2) { std::fprintf(stderr, "usage: ref_dump <outdir> [data dir]\n"); return 2; }
     g_out = argv[1];
     std::filesystem::create_directories(g_out);

@@ -472,9 +472,15 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const unsigned long long queued = P.queueCounters[PRIMARY ? Q_GAVE_UP : Q_SHADOW_ITEMS];
-    // camera rays that gave up are long by construction: a quarter of the slots gives the stream enough pairs, and four
-    // times as many waves share the (often few) rays
-    const uint32_t raysPerPacket = PRIMARY ? STREAM_RAYS / 4 : STREAM_RAYS;
+    // camera rays that gave up are long by construction: a quarter of the slots at most gives the stream enough pairs
+    // and spreads the (often few) rays over more waves ...
+    uint32_t raysPerPacket = STREAM_RAYS;
+    if (PRIMARY) {
+        // ... down to one ray per packet when there are fewer rays than waves (a single such ray can have thousands of
+        // pairs; a wave that holds sixteen of them is the last one running)
+        const unsigned long long perWave = queued / (2ull * gridDim.x);
+        raysPerPacket = perWave < 1ull ? 1u : (perWave > STREAM_RAYS / 4 ? STREAM_RAYS / 4 : uint32_t(perWave));
+    }
     const unsigned long long nPackets = (queued + raysPerPacket - 1) / raysPerPacket;
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)

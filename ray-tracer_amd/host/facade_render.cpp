@@ -4,6 +4,9 @@
 //   facade_render <scene.rtscene> <out.f32> <width> <height> <feature flags, comma separated> [out.bmp]
 // Second form, no rendering: reads a Wavefront OBJ file with loadMesh and writes the meshes as a binary scene.
 //   facade_render --obj <file.obj> <0|1: centre and normalise> <out.rtscene>
+// Third and fourth form: an image file through Image(path); a prebuilt scene through loadScenePrebuilt.
+//   facade_render --image <file.png|jpg> <out.bin>
+//   facade_render --table <scene type number> <data dir> <0|1: sky box> <out.rtscene>
 #include "rt_facade.h"
 
 #include <cstdio>
@@ -11,8 +14,11 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <variant>
 
 using namespace rtamd;
+
+static int write_meshes(const std::vector<Mesh>& meshes, const char* outFile);
 
 static int convert_obj(const char* objFile, bool normalize, const char* outFile)
 {
@@ -22,6 +28,65 @@ static int convert_obj(const char* objFile, bool normalize, const char* outFile)
     } catch (const std::exception&) {
         return 1;
     }
+    return write_meshes(meshes, outFile);
+}
+
+// Image(path): int32 width, int32 height, then the RGB bytes.  Exit status 3 when the file cannot be decoded.
+static int convert_image(const char* imageFile, const char* outFile)
+{
+    try {
+        const Image img { std::filesystem::path(imageFile) };
+        std::ofstream out(outFile, std::ios::binary);
+        const int32_t size[2] = { img.width, img.height };
+        out.write(reinterpret_cast<const char*>(size), sizeof size);
+        out.write(reinterpret_cast<const char*>(img.rgb.data()), std::streamsize(img.rgb.size()));
+        return out ? 0 : 1;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
+}
+
+// loadScenePrebuilt: the meshes as a binary scene, lights and spheres as text lines (the 22 / 12 numbers per record
+// that the golden scene arrays hold), texture sizes.
+static int convert_table(int type, const char* dataDir, bool withSkybox, const char* outFile)
+{
+    Scene scene;
+    try {
+        scene = loadScenePrebuilt(SceneType(type), dataDir, withSkybox);
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 3;
+    }
+    for (const auto& l : scene.lights) {
+        float rec[22] = { 0 };
+        auto put = [&](int at, const vec3& v) { rec[at] = v.x; rec[at + 1] = v.y; rec[at + 2] = v.z; };
+        if (std::holds_alternative<PointLight>(l)) {
+            const auto& p = std::get<PointLight>(l);
+            put(1, p.position); put(4, p.color);
+        } else if (std::holds_alternative<SegmentLight>(l)) {
+            const auto& g = std::get<SegmentLight>(l);
+            rec[0] = 1; put(1, g.endpoint0); put(4, g.endpoint1); put(7, g.color0); put(10, g.color1);
+        } else {
+            const auto& p = std::get<ParallelogramLight>(l);
+            rec[0] = 2; put(1, p.v0); put(4, p.edge01); put(7, p.edge02); put(10, p.color0); put(13, p.color1); put(16, p.color2); put(19, p.color3);
+        }
+        std::printf("light");
+        for (float v : rec) std::printf(" %.9g", double(v));
+        std::printf("\n");
+    }
+    for (const Sphere& sp : scene.spheres)
+        std::printf("sphere %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", double(sp.center.x), double(sp.center.y), double(sp.center.z), double(sp.radius),
+            double(sp.material.kd.x), double(sp.material.kd.y), double(sp.material.kd.z), double(sp.material.ks.x), double(sp.material.ks.y), double(sp.material.ks.z),
+            double(sp.material.shininess), double(sp.material.transparency));
+    for (const Mesh& m : scene.meshes)
+        if (m.material.kdTexture) std::printf("texture %d %d\n", m.material.kdTexture->width, m.material.kdTexture->height);
+    for (const Image& face : scene.skybox) std::printf("skybox %d %d\n", face.width, face.height);
+    return write_meshes(scene.meshes, outFile);
+}
+
+static int write_meshes(const std::vector<Mesh>& meshes, const char* outFile)
+{
     std::ofstream out(outFile, std::ios::binary);
     out.write("RTSCENE1", 8);
     const uint32_t counts[8] = { uint32_t(meshes.size()), 0, 0, 0, 0, 0, 0, 0 };
@@ -43,6 +108,8 @@ static int convert_obj(const char* objFile, bool normalize, const char* outFile)
 int main(int argc, char** argv)
 {
     if (argc == 5 && std::strcmp(argv[1], "--obj") == 0) return convert_obj(argv[2], std::atoi(argv[3]) != 0, argv[4]);
+    if (argc == 4 && std::strcmp(argv[1], "--image") == 0) return convert_image(argv[2], argv[3]);
+    if (argc == 6 && std::strcmp(argv[1], "--table") == 0) return convert_table(std::atoi(argv[2]), argv[3], std::atoi(argv[4]) != 0, argv[5]);
     if (argc < 6) {
         std::fprintf(stderr, "usage: facade_render scene out.f32 W H flags [out.bmp]\n");
         return 2;

@@ -18,8 +18,7 @@
 // texture coordinate are all equal, the geometric normal where the file has none, optional centring and
 // scaling to the unit sphere in fp32.
 //
-// Texture files are not decoded here (no image codec in this library): the material keeps the file name in
-// Material::kdTextureFile and the caller attaches the pixels.
+// A material's texture file (map_Kd) is decoded by Image(path) and attached like the reference does (:131-133).
 #include "rt_facade.h"
 
 #include <cmath>
@@ -450,6 +449,7 @@ std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNorm
 {
     if (!std::filesystem::exists(file)) fail("File " + file.string() + " does not exist.");
     const ObjFile obj = parse_obj(file);
+    const std::filesystem::path baseDir = file.parent_path();
     auto position = [&](int i) { return vec3(obj.v[size_t(i) * 3], obj.v[size_t(i) * 3 + 1], obj.v[size_t(i) * 3 + 2]); };
 
     std::vector<Mesh> out;
@@ -500,6 +500,7 @@ std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNorm
                 const ObjMaterial& m = obj.materials[size_t(materialId)];
                 mesh.material.kd = { m.diffuse[0], m.diffuse[1], m.diffuse[2] };
                 mesh.material.kdTextureFile = m.diffuseTexture;
+                if (!m.diffuseTexture.empty()) mesh.material.kdTexture = std::make_shared<Image>(baseDir / m.diffuseTexture);
                 mesh.material.ks = { m.specular[0], m.specular[1], m.specular[2] };
                 mesh.material.shininess = m.shininess;
                 mesh.material.transparency = m.dissolve;

@@ -46,6 +46,9 @@ struct Ray {
 
 struct Image {
     Image(int w, int h, std::vector<uint8_t> rgbBytes) : width(w), height(h), rgb(std::move(rgbBytes)) {}
+    // PNG or JPEG file -> the bytes stb_image 2.27 gives the reference for three channels (reference
+    // framework/src/image.cpp:13-35).  Throws std::exception when the file is missing or cannot be decoded.
+    explicit Image(const std::filesystem::path& filePath);
     int width, height;
     std::vector<uint8_t> rgb; // row-major RGB bytes; texel value = byte / 255.0f
 };
@@ -60,7 +63,7 @@ struct Material {
     float shininess { 1.0f };
     float transparency { 1.0f };
     std::shared_ptr<Image> kdTexture;
-    std::string kdTextureFile; // no counterpart: map_Kd file name as loadMesh read it (this library decodes no image files)
+    std::string kdTextureFile; // no counterpart: map_Kd file name as loadMesh read it
 };
 struct Mesh {
     std::vector<Vertex> vertices;
@@ -203,9 +206,20 @@ const rt_stats& lastRenderStats();
 // Wavefront OBJ (+ MTL) file -> one Mesh per material run, as the reference's loadMesh does it (reference
 // framework/src/mesh.cpp:52-149 on tinyobjloader 2.0.0): same vertices in the same order, same triangles, same
 // materials; centerAndNormalize applies the reference's centring and scaling to the unit sphere (:151-176).
-// Texture files are not decoded: Material::kdTextureFile carries the name, kdTexture stays empty.  Throws
-// std::exception like the reference when the file is missing or malformed.
+// A material's map_Kd file is decoded into kdTexture (:131-133; the file name is kept in kdTextureFile).  Throws
+// std::exception like the reference when the OBJ file or a texture file is missing or malformed.
 std::vector<Mesh> loadMesh(const std::filesystem::path& file, bool centerAndNormalize = false);
+
+// The same decoder on bytes in memory (no counterpart).
+Image decodeImage(const uint8_t* data, size_t size);
+
+// The reference's table of prebuilt scenes (reference src/scene.cpp:5-119): OBJ file, unit-sphere normalisation
+// and lights per SceneType, and the six sky box faces right/left/top/bottom/front/back.jpg.  The reference reads
+// the sky box from its compile-time DATA_DIR; here it comes from dataDir as well, and withSkybox = false leaves it
+// out (a scene without sky box renders black where the reference samples the cube map).
+Scene loadScenePrebuilt(SceneType type, const std::filesystem::path& dataDir, bool withSkybox = true);
+// One OBJ file with the caller's lights (reference src/scene.cpp:121-130).
+Scene loadSceneFromFile(const std::filesystem::path& path, const std::vector<std::variant<PointLight, SegmentLight, ParallelogramLight>>& lights);
 
 // Flat binary scene file written by tests (meshes, materials, textures, spheres, lights, skybox); an extension
 // used where the reference would call loadScenePrebuilt with its OBJ files.

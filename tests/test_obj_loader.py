@@ -22,7 +22,12 @@ def load_with_facade(tmp_path, obj_file, normalize):
     out = str(tmp_path / "meshes.rtscene")
     res = subprocess.run([DRIVER, "--obj", obj_file, str(int(normalize)), out], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
-    b = open(out, "rb").read()
+    return read_meshes(out)
+
+
+def read_meshes(path):
+    """vertices, triangles, mesh table, materials of a binary scene the facade driver wrote"""
+    b = open(path, "rb").read()
     assert b[:8] == b"RTSCENE1"
     n = struct.unpack_from("<8I", b, 8)[0]
     off = 40
