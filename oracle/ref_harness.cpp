@@ -54,6 +54,7 @@
 #include "bvh_interface.h"
 #undef private
 #include "bloom.h"
+#include "config.h"
 #include "dof.h"
 #include "draw.h"
 #include "environment_mapping.h"
@@ -794,6 +795,11 @@ int main(int argc, char** argv)
         npy_u32(prefix + "triangles", { tris.size() / 3, 3 }, tris.data());
         npy_i32(prefix + "mesh_table", { meshTable.size() / 5, 5 }, meshTable.data());
         npy_f32(prefix + "materials", { materials.size() / 8, 8 }, materials.data());
+        return 0;
+    }
+    if (argc == 3 && std::string(argv[1]) == "--config") {
+        // ref_dump --config <file.toml>: the reference's readConfigFile and its printer
+        std::cout << readConfigFile(argv[2]);
         return 0;
     }
     if (argc == 4 && std::string(argv[1]) == "--image") {
