@@ -1,8 +1,10 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace rt {
 
@@ -69,50 +71,87 @@ struct PrimBounds {
     int32_t prim, mesh;
 };
 
+// One subtree in reference order (node before its left subtree before its right subtree, primitives in leaf
+// order), with indices counted from the subtree's own first node / first primitive.
+struct Subtree {
+    std::vector<rt_node_record> nodes;
+    std::vector<rt_prim_ref> prims;
+    int numLevels = 0, numLeaves = 0;
+};
+
+struct Bounds {
+    vec3 lo, hi;
+};
+
 struct Builder {
     const std::vector<PrimBounds>& prims;
-    std::vector<int> order; // permutation of prims being partitioned in place
-    HostBvh& out;
+    std::vector<int> order; // permutation of prims being partitioned in place; a subtree owns its range of it
     int maxLevel, sahBins;
     bool sah;
+    int spawnLevels; // subtrees above this level are built by a thread of their own
+    size_t spawnMinimum;
 
-    void bounds(size_t first, size_t last, vec3& lo, vec3& hi) const
+    static Bounds empty() { return { splat3(FLT_MAX), splat3(-FLT_MAX) }; }
+    static void grow(Bounds& b, const PrimBounds& p)
     {
-        lo = splat3(FLT_MAX);
-        hi = splat3(-FLT_MAX);
-        for (size_t i = first; i < last; i++) {
-            const PrimBounds& p = prims[size_t(order[i])];
-            lo = make3(std::fmin(lo.x, p.lo.x), std::fmin(lo.y, p.lo.y), std::fmin(lo.z, p.lo.z));
-            hi = make3(std::fmax(hi.x, p.hi.x), std::fmax(hi.y, p.hi.y), std::fmax(hi.z, p.hi.z));
-        }
+        b.lo = make3(std::fmin(b.lo.x, p.lo.x), std::fmin(b.lo.y, p.lo.y), std::fmin(b.lo.z, p.lo.z));
+        b.hi = make3(std::fmax(b.hi.x, p.hi.x), std::fmax(b.hi.y, p.hi.y), std::fmax(b.hi.z, p.hi.z));
     }
-    static float area(vec3 lo, vec3 hi)
+    Bounds bounds(size_t first, size_t last) const
     {
-        vec3 e = hi - lo;
-        return dot(hi - lo, make3(e.y, e.z, e.x));
+        Bounds b = empty();
+        for (size_t i = first; i < last; i++) grow(b, prims[size_t(order[i])]);
+        return b;
     }
+    static float area(const Bounds& b)
+    {
+        vec3 e = b.hi - b.lo;
+        return dot(b.hi - b.lo, make3(e.y, e.z, e.x));
+    }
+    // std::sort of the range by centroid coordinate, as the reference does it on its primitive list.  The sort
+    // runs on (coordinate, index) pairs: the algorithm sees the same comparison results as with an indirect
+    // comparator, so it makes the same moves (equal coordinates included) without chasing an index per comparison.
     void sortAxis(size_t first, size_t last, int axis)
     {
-        std::sort(order.begin() + long(first), order.begin() + long(last),
-            [&](int a, int b) { return comp(prims[size_t(a)].centroid, axis) < comp(prims[size_t(b)].centroid, axis); });
+        struct Keyed {
+            float key;
+            int index;
+        };
+        thread_local std::vector<Keyed> keyed;
+        keyed.resize(last - first);
+        for (size_t i = first; i < last; i++) keyed[i - first] = { comp(prims[size_t(order[i])].centroid, axis), order[i] };
+        std::sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+        for (size_t i = first; i < last; i++) order[i] = keyed[i - first].index;
     }
 
     // SAH split search over the three axes; returns the split offset and leaves the range sorted on the
-    // winning axis (reference …hierarchy.cpp:133-190).
-    size_t sahSplit(size_t first, size_t last, vec3 lo, vec3 hi)
+    // winning axis (reference …hierarchy.cpp:133-190).  The reference recomputes both boxes for every candidate;
+    // here the boxes of all prefixes and suffixes of the sorted range are made in two passes (min and max do not
+    // depend on the order they are taken in).
+    size_t sahSplit(size_t first, size_t last, const Bounds& whole)
     {
         const size_t count = last - first;
         float best = FLT_MAX;
-        const float invParent = 1.0f / area(lo, hi);
+        const float invParent = 1.0f / area(whole);
         int bestAxis = -1;
         size_t split = 0;
+        thread_local std::vector<Bounds> prefix, suffix;
+        prefix.resize(count + 1);
+        suffix.resize(count + 1);
         for (int axis = 0; axis < 3; axis++) {
             sortAxis(first, last, axis);
+            prefix[0] = empty();
+            for (size_t k = 0; k < count; k++) {
+                prefix[k + 1] = prefix[k];
+                grow(prefix[k + 1], prims[size_t(order[first + k])]);
+            }
+            suffix[count] = empty();
+            for (size_t k = count; k > 0; k--) {
+                suffix[k - 1] = suffix[k];
+                grow(suffix[k - 1], prims[size_t(order[first + k - 1])]);
+            }
             auto consider = [&](size_t k) {
-                vec3 llo, lhi, rlo, rhi;
-                bounds(first, first + k, llo, lhi);
-                bounds(first + k, last, rlo, rhi);
-                float cost = (area(llo, lhi) * float(int(k)) + area(rlo, rhi) * float(count - k)) * invParent;
+                float cost = (area(prefix[k]) * float(int(k)) + area(suffix[k]) * float(count - k)) * invParent;
                 if (cost < best) {
                     best = cost;
                     bestAxis = axis;
@@ -138,17 +177,35 @@ struct Builder {
         return split;
     }
 
-    void node(size_t first, size_t last, int level, int parent)
+    // appends `sub` behind the nodes and primitives `into` already has
+    static int splice(Subtree& into, const Subtree& sub)
+    {
+        const int32_t nodeBase = int32_t(into.nodes.size()), primBase = int32_t(into.prims.size());
+        for (rt_node_record rec : sub.nodes) {
+            if (rec.is_leaf) {
+                rec.a += primBase;
+            } else {
+                rec.a += nodeBase;
+                rec.b += nodeBase;
+            }
+            into.nodes.push_back(rec);
+        }
+        into.prims.insert(into.prims.end(), sub.prims.begin(), sub.prims.end());
+        into.numLevels = std::max(into.numLevels, sub.numLevels);
+        into.numLeaves += sub.numLeaves;
+        return nodeBase;
+    }
+
+    void node(size_t first, size_t last, int level, int parent, Subtree& out)
     {
         out.numLevels = std::max(out.numLevels, level + 1);
         const int self = int(out.nodes.size());
         rt_node_record rec;
         std::memset(&rec, 0, sizeof rec);
         rec.level = level;
-        vec3 lo, hi;
-        bounds(first, last, lo, hi);
-        rec.lower[0] = lo.x; rec.lower[1] = lo.y; rec.lower[2] = lo.z;
-        rec.upper[0] = hi.x; rec.upper[1] = hi.y; rec.upper[2] = hi.z;
+        const Bounds box = bounds(first, last);
+        rec.lower[0] = box.lo.x; rec.lower[1] = box.lo.y; rec.lower[2] = box.lo.z;
+        rec.upper[0] = box.hi.x; rec.upper[1] = box.hi.y; rec.upper[2] = box.hi.z;
         if (parent >= 0) {
             rt_node_record& p = out.nodes[size_t(parent)];
             if (p.a < 0) p.a = self; else p.b = self;
@@ -170,14 +227,25 @@ struct Builder {
         rec.a = rec.b = -1;
         size_t split;
         if (sah) {
-            split = sahSplit(first, last, lo, hi);
+            split = sahSplit(first, last, box);
         } else {
             sortAxis(first, last, level % 3);
             split = count / 2;
         }
         out.nodes.push_back(rec);
-        node(first, first + split, level + 1, self);
-        node(first + split, last, level + 1, self);
+        if (level < spawnLevels && count >= spawnMinimum) {
+            // the two halves own disjoint ranges of `order`: the left one goes to another thread, and both are
+            // put behind this node in the reference's order afterwards
+            Subtree left, right;
+            std::thread other([&] { node(first, first + split, level + 1, -1, left); });
+            node(first + split, last, level + 1, -1, right);
+            other.join();
+            out.nodes[size_t(self)].a = splice(out, left);
+            out.nodes[size_t(self)].b = splice(out, right);
+            return;
+        }
+        node(first, first + split, level + 1, self, out);
+        node(first + split, last, level + 1, self, out);
     }
 };
 
@@ -211,11 +279,22 @@ void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out)
         const vec3 c = load3(sp.center);
         prims.push_back(PrimBounds { c - splat3(sp.radius), c + splat3(sp.radius), c, int32_t(s), -1 });
     }
-    Builder b { prims, std::vector<int>(prims.size()), out, opt.max_level, opt.sah_bins, opt.sah_binning != 0 };
+    // host threads: 2^spawnLevels subtrees at most run side by side (a GPU box gives a process 16 cores)
+    unsigned threads = std::thread::hardware_concurrency();
+    if (const char* env = std::getenv("RT_BUILD_THREADS")) threads = unsigned(std::max(1, std::atoi(env)));
+    threads = std::min(threads < 1 ? 1u : threads, 16u);
+    int spawnLevels = 0;
+    while ((1u << (spawnLevels + 1)) <= threads) spawnLevels++;
+    Builder b { prims, std::vector<int>(prims.size()), opt.max_level, opt.sah_bins, opt.sah_binning != 0, spawnLevels, size_t(4096) };
     std::iota(b.order.begin(), b.order.end(), 0);
-    out.nodes.reserve(prims.size() * 2 + 1);
-    out.prims.reserve(prims.size());
-    b.node(0, prims.size(), 0, -1);
+    Subtree tree;
+    tree.nodes.reserve(prims.size() * 2 + 1);
+    tree.prims.reserve(prims.size());
+    b.node(0, prims.size(), 0, -1, tree);
+    out.nodes = std::move(tree.nodes);
+    out.prims = std::move(tree.prims);
+    out.numLevels = tree.numLevels;
+    out.numLeaves = tree.numLeaves;
 }
 
 void flatten_bvh(const HostScene& scene, const HostBvh& bvh, FlatBvh& out)
