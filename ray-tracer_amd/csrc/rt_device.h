@@ -798,6 +798,21 @@ __device__ __forceinline__ void camera_ray(const FrameParams& P, float px, float
     d = rotate(P.camQ, c);
 }
 
+// Lens ray k of a pixel whose centre ray is (o, d): getEyeFrame, reference src/dof.cpp:21-51.
+__device__ __forceinline__ void lens_ray(const FrameParams& P, uint32_t pixelKey, int k, vec3& o, vec3& d)
+{
+    const vec3 w = normalize(d);
+    const vec3 up = load3(P.camUp), left = load3(P.camLeft);
+    const float side = P.p.dof_f / (P.p.dof_aperture * 6.0f);
+    const float offset = -side / 2.0f;
+    const vec3 focus = o + w * P.p.dof_f;
+    const double u0 = rng_unit(rng_u32(pixelKey, 0, RNG_STREAM_DOF, uint32_t(2 * k)));
+    const double u1 = rng_unit(rng_u32(pixelKey, 0, RNG_STREAM_DOF, uint32_t(2 * k + 1)));
+    const vec3 eye = (o + float(double(offset) + u0 * double(side)) * up) + float(double(offset) + u1 * double(side)) * left;
+    d = normalize(focus - eye);
+    o = eye;
+}
+
 // Colour of sample `sidx` of pixel (x, y):
 //   supersampling on  -> sample (i, j) = (sidx / n, sidx % n) of calculateColor's n x n loop;
 //   depth of field on -> sample 0 is the centre ray (whose first hit distance doubles as the reference's
@@ -826,20 +841,7 @@ __device__ vec3 render_sample(const FrameParams& P, int x, int y, int sidx, Stac
         const float py = float(y) / H * 2.0f - 1.0f;
         camera_ray(P, px, py, o, d);
         rng.randCounter = 2; // indices 0 and 1 belong to the pixel jitter
-        if (P.f.depth_of_field && sidx > 0) {
-            // getEyeFrame, reference src/dof.cpp:21-51
-            const int k = sidx - 1;
-            const vec3 w = normalize(d);
-            const vec3 up = load3(P.camUp), left = load3(P.camLeft);
-            const float side = P.p.dof_f / (P.p.dof_aperture * 6.0f);
-            const float offset = -side / 2.0f;
-            const vec3 focus = o + w * P.p.dof_f;
-            const double u0 = rng_unit(rng_u32(rng.pixelKey, 0, RNG_STREAM_DOF, uint32_t(2 * k)));
-            const double u1 = rng_unit(rng_u32(rng.pixelKey, 0, RNG_STREAM_DOF, uint32_t(2 * k + 1)));
-            const vec3 eye = (o + float(double(offset) + u0 * double(side)) * up) + float(double(offset) + u1 * double(side)) * left;
-            d = normalize(focus - eye);
-            o = eye;
-        }
+        if (P.f.depth_of_field && sidx > 0) lens_ray(P, rng.pixelKey, sidx - 1, o, d);
     }
     cnt.primary++;
     const float dlen = length(d);
@@ -885,7 +887,15 @@ __device__ __forceinline__ void sample_camera_ray(const FrameParams& P, int x, i
         const float py = float(y) / H * 2.0f - 1.0f;
         camera_ray(P, px, py, o, d);
         rng.randCounter = 2;
+        if (P.f.depth_of_field && sidx > 0) lens_ray(P, rng.pixelKey, sidx - 1, o, d);
     }
+}
+
+// The reference's test whether a pixel gets its lens rays at all (render.cpp:110): the centre ray hit something at
+// distance t and that point is further than P.p.dof from the focal distance.
+__device__ __forceinline__ bool dof_flag(const FrameParams& P, vec3 d, float t)
+{
+    return t != FLT_MAX && fabsf(P.p.dof_f - length(d) * t) > P.p.dof;
 }
 
 // y coordinate (counted from the bottom, as the camera and the random streams use it) of a local row

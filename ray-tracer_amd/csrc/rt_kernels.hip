@@ -157,7 +157,10 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
         const LaneId id = lane_id(P, logical);
         int slot = -1;
         float t = FLT_MAX;
-        if (id.valid) {
+        // depth of field: the lens rays of a pixel are traced only when its centre ray (sample 0, an earlier pass) said so
+        const bool dof = P.f.depth_of_field != 0;
+        const bool live = id.valid && !(dof && id.sidx > 0 && P.dofFlags[id.pix] == 0);
+        if (live) {
             Rng rng;
             vec3 o, d;
             sample_camera_ray(P, id.x, id.y, id.sidx, rng, o, d);
@@ -165,6 +168,8 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
             cnt.primary++;
             Attr attr;
             slot = traverse<PRUNE, false, COUNT, false, true>(P.scene, r, t, st, cnt, attr, P.primaryBudget);
+            // (a centre ray that gave up gets its flag from the kernel that finishes it)
+            if (dof && id.sidx == 0 && slot != TRAVERSE_GAVE_UP) P.dofFlags[id.pix] = dof_flag(P, d, slot >= 0 ? t : FLT_MAX) ? 1 : 0;
             if (slot == -1) {
                 const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, d) : splat3(0.0f);
                 float* out = sample_slot(P, id.pix, id.sidx);
@@ -223,6 +228,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
         e.slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
         e.t = t;
         P.queue[q] = e;
+        if (P.f.depth_of_field && sidx == 0) P.dofFlags[pix] = dof_flag(P, r.d, e.slot >= 0 ? t : FLT_MAX) ? 1 : 0;
         if (e.slot < 0) {
             // cannot happen (the traversal meets the primitive the stream kernel found, or an earlier one, before
             // anything is pruned); the later passes skip such an entry
@@ -666,6 +672,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
             // a camera ray that met no primitive is final (sky or black); the others queue up for k_closest (one
             // atomic per wave)
             if (have && !found) {
+                if (P.f.depth_of_field && P.sampleBegin + int(work / nPix) == 0) P.dofFlags[work % nPix] = 0;
                 const vec3 c = (P.f.environment_mapping && P.p.enabled_skybox) ? skybox_color(P.scene, r.d) : splat3(0.0f);
                 float* out = sample_slot(P, size_t(work % nPix), P.sampleBegin + int(work / nPix));
                 out[0] = c.x;
@@ -936,7 +943,7 @@ void size_pair_stack(FrameParams& P)
 
 bool direct_only(const FrameParams& P)
 {
-    return !(P.f.recursive || P.f.glossy || P.f.transparency || P.f.depth_of_field || (P.f.environment_mapping && P.p.enabled_refl_map));
+    return !(P.f.recursive || P.f.glossy || P.f.transparency || (P.f.environment_mapping && P.p.enabled_refl_map));
 }
 
 hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* splitEvents, bool* splitRecorded)
@@ -971,7 +978,14 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     if (P.f.depth_of_field && !P.f.multiple_rays && P.samplesPerPixel > 1) {
         // the centre rays decide per pixel whether the lens rays are traced at all
         if ((e = pass(0, 1)) != hipSuccess) return e;
-        if ((e = pass(1, P.samplesPerPixel)) != hipSuccess) return e;
+        int chunk = P.samplesPerPixel - 1;
+        if (split) {
+            // bound the hit queue, as below
+            chunk = int(P.queueCapacity / (size_t(rows) * size_t(P.width)));
+            if (chunk < 1) chunk = 1;
+        }
+        for (int sb = 1; sb < P.samplesPerPixel; sb += chunk)
+            if ((e = pass(sb, sb + chunk < P.samplesPerPixel ? sb + chunk : P.samplesPerPixel)) != hipSuccess) return e;
     } else if (split) {
         // bound the hit queue: at most queueCapacity (pixel, sample) pairs per pass
         const size_t nPix = size_t(rows) * size_t(P.width);
