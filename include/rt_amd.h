@@ -227,7 +227,10 @@ rt_status rt_render_blocks(const rt_bvh* bvh, const rt_camera* camera, const rt_
     const rt_features* features, const rt_params* params, int32_t width, int32_t height, int32_t row_block,
     int32_t first_block, int32_t block_stride, float* out_rgb, int32_t device_ptr, void* stream, rt_stats* stats);
 
-/* addBloom (src/bloom.cpp:88-114) on a full width x height float RGB frame, in place. */
+/* addBloom (src/bloom.cpp:88-114) on a full width x height float RGB frame, in place.  With a device pointer the
+ * work is queued on `stream` and the call returns without waiting; with a host pointer it returns when the pixels
+ * are back.  The frame copy the filter reads from is a per-device buffer the library keeps between calls (allocated
+ * on the first call on a device and when a larger frame arrives). */
 rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params* params, int32_t device_ptr, void* stream);
 
 #ifdef __cplusplus

@@ -14,6 +14,7 @@ from .capi import (  # noqa: F401
     Light,
     Params,
     Ray,
+    RtError,
     SceneData,
     Stats,
     HIT_DTYPE,

@@ -425,3 +425,7 @@ class Library:
         h, w = img.shape[0], img.shape[1]
         self.check(self.lib.rt_bloom(img.ctypes.data, w, h, C.byref(params), 0, None))
         return img
+
+    def bloom_device(self, ptr, width, height, params, stream=None):
+        """rt_bloom in place on a device frame (queued on `stream`, no wait)."""
+        self.check(self.lib.rt_bloom(ptr, width, height, C.byref(params), 1, stream))

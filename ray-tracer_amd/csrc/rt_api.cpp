@@ -89,7 +89,7 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, bloomWeights;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
 };
 
@@ -275,6 +275,56 @@ rt_status upload_bvh(rt_bvh* b)
 
 } // namespace
 
+
+// ---- per-device state of the library (not tied to a scene or hierarchy handle) -----------------------------------
+namespace {
+
+enum { MAX_DEVICES = 64 };
+struct DeviceState {
+    std::mutex lock;
+    DevBuf bloomSrc, bloomDst;      // rt_bloom: frame copy (and result staging for host frames), grown on demand
+    hipEvent_t bloomDone = nullptr; // recorded after rt_bloom's last use of bloomSrc
+};
+DeviceState g_devices[MAX_DEVICES];
+
+rt_status device_state(DeviceState** out)
+{
+    int dev = 0;
+    RT_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(RT_ERR_LIMIT, "device index beyond the library's device table");
+    *out = &g_devices[dev];
+    return RT_OK;
+}
+
+// gaussianKernel, reference src/bloom.cpp:14-34: the per-axis factors and the sum of all their products
+rt_status fill_bloom(const rt_params& p, BloomParams& bp)
+{
+    if (p.bloom_size < 0 || p.bloom_size > BLOOM_MAX_SIZE) return fail(RT_ERR_LIMIT, "bloom_size must be in [0, " + std::to_string(int(BLOOM_MAX_SIZE)) + "]");
+    std::memset(&bp, 0, sizeof bp);
+    bp.threshold = p.bloom_threshold;
+    bp.scale = p.bloom_scale;
+    bp.size = p.bloom_size;
+    bp.gaussian = p.bloom_gaussian;
+    bp.debug = p.bloom_debug;
+    bp.denom = 1.0f;
+    if (p.bloom_gaussian) {
+        const int k = p.bloom_size, size = 2 * k + 1;
+        const float sd = float(std::pow(double(p.bloom_sigma), 2.0));
+        const double spread = 1.0 / double(2 * sd);
+        for (int i = 0; i < size; i++) {
+            const int x = i - k;
+            bp.f[i] = float(std::exp(double(-x * x) * spread));
+        }
+        float denom = 0;
+        for (int i = 0; i < size; i++)
+            for (int j = 0; j < size; j++) denom += bp.f[j] * bp.f[i];
+        bp.denom = denom;
+    }
+    return RT_OK;
+}
+
+} // namespace
+
 extern "C" {
 
 const char* rt_last_error(void) { return g_error.c_str(); }
@@ -360,7 +410,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->bloomWeights })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -613,52 +663,29 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
 rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params* params, int32_t devicePtr, void* stream)
 {
     if (!pixels || !params || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_bloom: bad argument");
-    if (params->bloom_size < 0 || params->bloom_size > 16) return fail(RT_ERR_LIMIT, "bloom_size must be in [0, 16]");
+    BloomParams bp;
+    rt_status st = fill_bloom(*params, bp);
+    if (st != RT_OK) return st;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int k = params->bloom_size, size = 2 * k + 1;
-    // gaussianKernel, reference src/bloom.cpp:14-48 (weights[j*size+i] = gaus[j][i])
-    std::vector<float> g(size_t(size) * size_t(size), 0.0f);
-    if (params->bloom_gaussian) {
-        const float sd = float(std::pow(double(params->bloom_sigma), 2.0));
-        const double spread = 1.0 / double(2 * sd);
-        float denom = 0;
-        for (int i = 0; i < size; i++) {
-            const int x = i - k;
-            const float valx = float(std::exp(double(-x * x) * spread));
-            for (int j = 0; j < size; j++) {
-                const int y = j - k;
-                const float valy = float(std::exp(double(-y * y) * spread));
-                g[size_t(i) * size_t(size) + size_t(j)] = valy * valx;
-                denom += valy * valx;
-            }
-        }
-        for (float& v : g) v /= denom;
-    }
     const size_t bytes = size_t(width) * size_t(height) * 12;
-    float *dSrc = nullptr, *dDst = nullptr, *dW = nullptr;
-    hipError_t e = hipMalloc(&dSrc, bytes);
-    if (e == hipSuccess && !devicePtr) e = hipMalloc(&dDst, bytes);
-    if (e == hipSuccess) e = hipMalloc(&dW, g.size() * sizeof(float));
-    auto cleanup = [&] {
-        if (dSrc) (void)hipFree(dSrc);
-        if (dDst) (void)hipFree(dDst);
-        if (dW) (void)hipFree(dW);
-    };
-    if (e != hipSuccess) {
-        cleanup();
-        return hip_fail(e, "rt_bloom: hipMalloc");
-    }
-    float* target = devicePtr ? pixels : dDst;
-    e = hipMemcpyAsync(dW, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(dSrc, pixels, bytes, devicePtr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) {
-        BloomParams bp { params->bloom_threshold, params->bloom_scale, k, params->bloom_gaussian, params->bloom_debug, dW };
-        e = launch_bloom(dSrc, target, width, height, bp, s);
-    }
-    if (e == hipSuccess && !devicePtr) e = hipMemcpyAsync(pixels, dDst, bytes, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    cleanup();
-    if (e != hipSuccess) return hip_fail(e, "rt_bloom");
+    DeviceState* d = nullptr;
+    if ((st = device_state(&d)) != RT_OK) return st;
+    // The filter reads neighbours of every pixel, so it cannot run in place: the frame is copied to a buffer this
+    // device keeps between calls (grown when a larger frame arrives) and filtered from there back into `pixels`.
+    // The buffer is shared by all calls on the device; an event orders a call behind the previous one's kernel
+    // when the two are on different streams.
+    std::lock_guard<std::mutex> guard(d->lock);
+    RT_HIP(d->bloomSrc.reserve(bytes));
+    if (!devicePtr) RT_HIP(d->bloomDst.reserve(bytes));
+    if (!d->bloomDone) RT_HIP(hipEventCreateWithFlags(&d->bloomDone, hipEventDisableTiming));
+    else RT_HIP(hipStreamWaitEvent(s, d->bloomDone, 0));
+    float* src = static_cast<float*>(d->bloomSrc.ptr);
+    float* target = devicePtr ? pixels : static_cast<float*>(d->bloomDst.ptr);
+    RT_HIP(hipMemcpyAsync(src, pixels, bytes, devicePtr ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    RT_HIP(launch_bloom(src, target, width, height, bp, s));
+    if (!devicePtr) RT_HIP(hipMemcpyAsync(pixels, target, bytes, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipEventRecord(d->bloomDone, s));
+    if (!devicePtr) RT_HIP(hipStreamSynchronize(s)); // host pixels must be complete on return
     return RT_OK;
 }
 

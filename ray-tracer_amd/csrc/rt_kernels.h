@@ -24,10 +24,15 @@ hipError_t launch_intersect(const FrameParams& P, const rt_ray* rays, uint64_t n
 // out[i*nSamples+s] = visibility of samples[s] from hit point i (rays carry the hit distance in t).
 hipError_t launch_visibility(const FrameParams& P, const rt_ray* rays, uint64_t n, const float* samples, int nSamples, uint8_t* out, hipStream_t stream);
 
+enum { BLOOM_MAX_SIZE = 16, BLOOM_MAX_TAPS = 2 * BLOOM_MAX_SIZE + 1 };
+// The Gaussian filter of reference src/bloom.cpp:14-48 is an outer product normalised by the sum of all products:
+// gaus[a][b] = (f[b] * f[a]) / denom with f[i] = exp(-(i - size)^2 / (2 sigma^2)).  The factors travel in the kernel
+// argument block and every block forms the (2*size+1)^2 weights in LDS with the same two fp32 operations, so no
+// weight table lives in device memory.
 struct BloomParams {
     float threshold, scale;
     int32_t size, gaussian, debug;
-    const float* weights; // (2*size+1)^2 filter weights, row j column i at [j*(2*size+1)+i] (device memory)
+    float f[BLOOM_MAX_TAPS], denom;
 };
 // dst = src + scale * filtered(mask(src)) (or just the filtered term in debug mode); src and dst differ.
 hipError_t launch_bloom(const float* src, float* dst, int width, int height, const BloomParams& bp, hipStream_t stream);

@@ -815,12 +815,17 @@ __global__ void __launch_bounds__(BLOCK) k_visibility(const FrameParams P, const
 // Bloom, reference src/bloom.cpp:52-114: thresholded copy of the frame filtered with a (2k+1)^2 kernel whose
 // vertical taps are strided by HEIGHT (bloom.cpp:66), bounds-checked on the flat index and on the column of
 // the centre pixel only.  Taps are accumulated column-offset-major like the reference's loops.
-__global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, float* __restrict__ dst, int width, int height, BloomParams bp)
+__global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, float* __restrict__ dst, int width, int height, const BloomParams bp)
 {
+    __shared__ float weights[BLOOM_MAX_TAPS * BLOOM_MAX_TAPS];
+    const int k = bp.size, size = 2 * k + 1;
+    // gaussianKernel, reference src/bloom.cpp:26-46: weights[a*size+b] = gaus[a][b] = (valy(b) * valx(a)) / denom
+    if (bp.gaussian)
+        for (int e = int(threadIdx.x); e < size * size; e += BLOCK) weights[e] = (bp.f[e % size] * bp.f[e / size]) / bp.denom;
+    __syncthreads();
     const long n = long(width) * long(height);
     const long idx = long(blockIdx.x) * BLOCK + threadIdx.x;
     if (idx >= n) return;
-    const int k = bp.size, size = 2 * k + 1;
     const float boxDiv = float(size * size);
     const int col = int(idx % width);
     vec3 avg = splat3(0.0f);
@@ -832,7 +837,7 @@ __global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, 
             if (x >= 0 && x < width && at >= 0 && at < n) {
                 vec3 c = load3(src + at * 3);
                 if (!(c.x > bp.threshold || c.y > bp.threshold || c.z > bp.threshold)) c = splat3(0.0f);
-                if (bp.gaussian) avg = avg + c * bp.weights[j * size + i];
+                if (bp.gaussian) avg = avg + c * weights[j * size + i];
                 else avg = avg + c / boxDiv;
             }
         }
