@@ -233,6 +233,16 @@ rt_status rt_render_blocks(const rt_bvh* bvh, const rt_camera* camera, const rt_
  * on the first call on a device and when a larger frame arrives). */
 rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params* params, int32_t device_ptr, void* stream);
 
+/* rt_bloom for callers that cannot allocate device memory (code under HIP graph capture, per-frame present loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result as rt_bloom on a DEVICE frame,
+ * queued on `stream`, no wait; it calls no hipMalloc / hipFree and nothing else that allocates: the frame copy goes
+ * to a static array inside the library's code object (rt_bloom_static_max_pixels() * 12 bytes = 3840 x 2160 pixels;
+ * every GPU the library runs on holds its copy until the process ends).  Larger frames are refused with RT_ERR_LIMIT.
+ * rt_init(device) resolves the array's address for that device; otherwise the first call on a device does.  All
+ * calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different streams) race. */
+rt_status rt_bloom_static(float* device_pixels, int32_t width, int32_t height, const rt_params* params, void* stream);
+uint64_t rt_bloom_static_max_pixels(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,6 +349,9 @@ class Library:
         lib.rt_render_blocks.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.POINTER(Features), C.POINTER(Params),
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
         lib.rt_bloom.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Params), C.c_int32, C.c_void_p]
+        lib.rt_bloom_static.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(Params), C.c_void_p]
+        lib.rt_bloom_static_max_pixels.restype = C.c_uint64
+        lib.rt_bloom_static_max_pixels.argtypes = []
         lib.rt_default_params.argtypes = [C.POINTER(Params)]
         lib.rt_default_params.restype = None
 
@@ -429,3 +432,7 @@ class Library:
     def bloom_device(self, ptr, width, height, params, stream=None):
         """rt_bloom in place on a device frame (queued on `stream`, no wait)."""
         self.check(self.lib.rt_bloom(ptr, width, height, C.byref(params), 1, stream))
+
+    def bloom_static(self, ptr, width, height, params, stream=None):
+        """rt_bloom_static: the same on a device frame without any allocation (frame size is limited)."""
+        self.check(self.lib.rt_bloom_static(ptr, width, height, C.byref(params), stream))

@@ -277,6 +277,15 @@ rt_status upload_bvh(rt_bvh* b)
 
 
 // ---- per-device state of the library (not tied to a scene or hierarchy handle) -----------------------------------
+// Scratch of rt_bloom_static: a copy of the frame being filtered.  The name is a host-side stand-in for the symbol;
+// host code uses the per-device address obtained with hipGetSymbolAddress (every GPU holds its own copy of the array
+// at its own address until the process ends).
+#define RT_STATIC_SCRATCH_BYTES (size_t(3840) * size_t(2160) * size_t(12))
+// (no kernel names it: they receive the address as an argument.  The host-side use in resolve_scratch() is what makes
+// the compiler keep the array in the code object under a name the loader can find; marking it `used` would keep it
+// as a local symbol, which hipGetSymbolAddress cannot resolve.)
+static __device__ __align__(256) unsigned char scratch[RT_STATIC_SCRATCH_BYTES];
+
 namespace {
 
 enum { MAX_DEVICES = 64 };
@@ -284,6 +293,7 @@ struct DeviceState {
     std::mutex lock;
     DevBuf bloomSrc, bloomDst;      // rt_bloom: frame copy (and result staging for host frames), grown on demand
     hipEvent_t bloomDone = nullptr; // recorded after rt_bloom's last use of bloomSrc
+    void* scratch = nullptr;        // this device's address of `scratch`
 };
 DeviceState g_devices[MAX_DEVICES];
 
@@ -293,6 +303,17 @@ rt_status device_state(DeviceState** out)
     RT_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return fail(RT_ERR_LIMIT, "device index beyond the library's device table");
     *out = &g_devices[dev];
+    return RT_OK;
+}
+
+// Address of the static scratch array on the current device (caller holds d.lock).
+rt_status resolve_scratch(DeviceState& d)
+{
+    if (d.scratch) return RT_OK;
+    void* p = nullptr;
+    RT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned a null address for the static scratch");
+    d.scratch = p;
     return RT_OK;
 }
 
@@ -363,7 +384,12 @@ rt_status rt_init(int32_t device)
     if (e != hipSuccess || n == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device index out of range");
     RT_HIP(hipSetDevice(device));
-    return RT_OK;
+    // set-up of the entry points that must not allocate later: this device's address of the static scratch
+    DeviceState* d = nullptr;
+    rt_status st = device_state(&d);
+    if (st != RT_OK) return st;
+    std::lock_guard<std::mutex> guard(d->lock);
+    return resolve_scratch(*d);
 }
 
 rt_status rt_scene_create(const rt_scene_desc* desc, rt_scene** out)
@@ -686,6 +712,34 @@ rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params
     if (!devicePtr) RT_HIP(hipMemcpyAsync(pixels, target, bytes, hipMemcpyDeviceToHost, s));
     RT_HIP(hipEventRecord(d->bloomDone, s));
     if (!devicePtr) RT_HIP(hipStreamSynchronize(s)); // host pixels must be complete on return
+    return RT_OK;
+}
+
+uint64_t rt_bloom_static_max_pixels(void) { return RT_STATIC_SCRATCH_BYTES / 12; }
+
+rt_status rt_bloom_static(float* devicePixels, int32_t width, int32_t height, const rt_params* params, void* stream)
+{
+    if (!devicePixels || !params || width <= 0 || height <= 0) return fail(RT_ERR_INVALID, "rt_bloom_static: bad argument");
+    const size_t bytes = size_t(width) * size_t(height) * 12;
+    if (bytes > RT_STATIC_SCRATCH_BYTES)
+        return fail(RT_ERR_LIMIT, "rt_bloom_static: frame of " + std::to_string(size_t(width) * size_t(height)) + " pixels exceeds the static scratch of " +
+                                      std::to_string(size_t(RT_STATIC_SCRATCH_BYTES / 12)) + " pixels; use rt_bloom");
+    BloomParams bp;
+    rt_status st = fill_bloom(*params, bp);
+    if (st != RT_OK) return st;
+    DeviceState* d = nullptr;
+    if ((st = device_state(&d)) != RT_OK) return st;
+    void* scratchPtr = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(d->lock);
+        if ((st = resolve_scratch(*d)) != RT_OK) return st;
+        scratchPtr = d->scratch;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // frame -> this device's copy of the static array -> filtered back into the frame; nothing needs to start at zero
+    // (the copy overwrites every byte the kernel reads)
+    RT_HIP(hipMemcpyAsync(scratchPtr, devicePixels, bytes, hipMemcpyDeviceToDevice, s));
+    RT_HIP(launch_bloom(static_cast<const float*>(scratchPtr), devicePixels, width, height, bp, s));
     return RT_OK;
 }
 
