@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <exception>
+#include <system_error>
 #include <thread>
 
 namespace rt {
@@ -237,9 +239,29 @@ struct Builder {
             // the two halves own disjoint ranges of `order`: the left one goes to another thread, and both are
             // put behind this node in the reference's order afterwards
             Subtree left, right;
-            std::thread other([&] { node(first, first + split, level + 1, -1, left); });
+            // If the system refuses another thread the left half is built here as well; the guard joins the
+            // thread also when the right half throws (a joinable std::thread must not be destroyed).
+            struct Joiner {
+                std::thread t;
+                std::exception_ptr error;
+                ~Joiner() { if (t.joinable()) t.join(); }
+            } other;
+            bool spawned = true;
+            try {
+                other.t = std::thread([&] {
+                    try {
+                        node(first, first + split, level + 1, -1, left);
+                    } catch (...) {
+                        other.error = std::current_exception();
+                    }
+                });
+            } catch (const std::system_error&) {
+                spawned = false;
+            }
+            if (!spawned) node(first, first + split, level + 1, -1, left);
             node(first + split, last, level + 1, -1, right);
-            other.join();
+            if (other.t.joinable()) other.t.join();
+            if (other.error) std::rethrow_exception(other.error);
             out.nodes[size_t(self)].a = splice(out, left);
             out.nodes[size_t(self)].b = splice(out, right);
             return;

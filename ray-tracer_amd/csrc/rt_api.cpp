@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -247,10 +248,12 @@ rt_status upload_bvh(rt_bvh* b)
     RT_HIP(upload(b->attrs, flat.attrs));
     RT_HIP(upload(b->primOrder, flat.primOrder));
     RT_HIP(b->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
-    RT_HIP(hipEventCreate(&b->evStart));
-    RT_HIP(hipEventCreate(&b->evMid));
-    for (hipEvent_t& e : b->evSplit) RT_HIP(hipEventCreate(&e));
-    RT_HIP(hipEventCreate(&b->evStop));
+    // (a retry after a partial failure keeps the events it already has)
+    if (!b->evStart) RT_HIP(hipEventCreate(&b->evStart));
+    if (!b->evMid) RT_HIP(hipEventCreate(&b->evMid));
+    for (hipEvent_t& e : b->evSplit)
+        if (!e) RT_HIP(hipEventCreate(&e));
+    if (!b->evStop) RT_HIP(hipEventCreate(&b->evStop));
     SceneView& v = b->view;
     v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
     v.prims = static_cast<const PrimRec*>(b->prims.ptr);
@@ -399,9 +402,17 @@ rt_status rt_scene_create(const rt_scene_desc* desc, rt_scene** out)
     rt_scene* s = new (std::nothrow) rt_scene;
     if (!s) return fail(RT_ERR_INVALID, "out of host memory");
     std::string err;
-    if (!copy_scene(*desc, s->host, err)) {
+    try {
+        if (!copy_scene(*desc, s->host, err)) {
+            delete s;
+            return fail(RT_ERR_INVALID, err);
+        }
+    } catch (const std::exception& e) { // nothing may unwind through the C ABI
         delete s;
-        return fail(RT_ERR_INVALID, err);
+        return fail(RT_ERR_LIMIT, std::string("rt_scene_create: ") + e.what());
+    } catch (...) {
+        delete s;
+        return fail(RT_ERR_LIMIT, "rt_scene_create: unknown failure");
     }
     *out = s;
     return RT_OK;
@@ -427,8 +438,16 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
     rt_bvh* b = new (std::nothrow) rt_bvh;
     if (!b) return fail(RT_ERR_INVALID, "out of host memory");
     b->scene = scene;
-    build_bvh(scene->host, opt, b->host);
-    flatten_bvh(scene->host, b->host, b->flat);
+    try {
+        build_bvh(scene->host, opt, b->host);
+        flatten_bvh(scene->host, b->host, b->flat);
+    } catch (const std::exception& e) { // out of host memory, thread limits: nothing may unwind through the C ABI
+        delete b;
+        return fail(RT_ERR_LIMIT, std::string("rt_bvh_build: ") + e.what());
+    } catch (...) {
+        delete b;
+        return fail(RT_ERR_LIMIT, "rt_bvh_build: unknown failure");
+    }
     *out = b;
     return RT_OK;
 }

@@ -859,15 +859,23 @@ size_t stack_bytes(const FrameParams& P, int threads)
 template <class K>
 uint32_t resident_blocks(K kernel, int threads, size_t lds)
 {
-    // the answer depends on (kernel, threads, lds, device); the last query of this kernel is remembered per thread
-    static thread_local struct { int threads, dev; size_t lds; uint32_t blocks; } last = { 0, -1, 0, 0 };
+    // The answer depends on (kernel, threads, lds, device).  The render kernels all have the same function type, so
+    // the kernel's address is part of the key; each thread remembers its recent queries (a frame alternates between
+    // a handful of them).
+    struct Entry { const void* kernel; int threads, dev; size_t lds; uint32_t blocks; };
+    constexpr int SLOTS = 16;
+    static thread_local Entry cache[SLOTS] = {};
+    static thread_local int next = 0;
     int perCu = 0, dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 256u * 8u;
-    if (last.dev == dev && last.threads == threads && last.lds == lds) return last.blocks;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    for (const Entry& e : cache)
+        if (e.kernel == key && e.dev == dev && e.threads == threads && e.lds == lds) return e.blocks;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 256u * 8u;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, lds) != hipSuccess || perCu < 1) perCu = 4;
-    last = { threads, dev, lds, uint32_t(perCu) * uint32_t(cus) };
-    return last.blocks;
+    cache[next] = Entry { key, threads, dev, lds, uint32_t(perCu) * uint32_t(cus) };
+    next = (next + 1) % SLOTS;
+    return uint32_t(perCu) * uint32_t(cus);
 }
 
 // Launches a render kernel with one-wave blocks: as many as are resident at once, or fewer if the pass is smaller.

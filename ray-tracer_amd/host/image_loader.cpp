@@ -504,6 +504,9 @@ private:
     {
         if (n == 0) return 0;
         if (m_bitCount < n) refill();
+        // the refill that meets a marker adds nothing; the next one pads with the zero bits that follow the data, so
+        // the count never goes negative (a negative count would make refill() shift by 32 or more)
+        if (m_bitCount < n) refill();
         const uint32_t v = m_bitBuffer >> (32 - n);
         m_bitBuffer <<= n;
         m_bitCount -= n;

@@ -387,6 +387,17 @@ ObjFile parse_obj(const std::filesystem::path& file)
         // smoothing groups, tags, lines and points do not reach the meshes
     }
     end_shape();
+    // Every index a face names must exist once the whole file is read (tinyobjloader and the reference index the
+    // arrays unchecked; a malformed file must fail here instead of reading outside them).  Relative indices further
+    // back than the first element arrive here negative.
+    const long nV = long(obj.v.size() / 3), nVn = long(obj.vn.size() / 3), nVt = long(obj.vt.size() / 2);
+    for (const ObjShape& sh : obj.shapes)
+        for (const Corner& c : sh.corners) {
+            if (c.v < 0 || c.v >= nV) fail("face names vertex " + std::to_string(c.v + 1) + " but the file has " + std::to_string(nV) + ": " + file.string());
+            // (a file without any vn / vt lines may still name them, like the reference's triangle.obj: those are ignored)
+            if (c.vn != -1 && nVn > 0 && (c.vn < 0 || c.vn >= nVn)) fail("face names a normal that does not exist: " + file.string());
+            if (c.vt != -1 && nVt > 0 && (c.vt < 0 || c.vt >= nVt)) fail("face names a texture coordinate that does not exist: " + file.string());
+        }
     return obj;
 }
 

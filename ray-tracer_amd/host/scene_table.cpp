@@ -1,5 +1,6 @@
 // The reference's prebuilt scenes and its one-file scene loader (reference src/scene.cpp:5-130): which OBJ file,
 // whether it is normalised to the unit sphere, and the lights, per SceneType.
+#include <stdexcept>
 #include "rt_facade.h"
 
 namespace rtamd {
@@ -41,6 +42,7 @@ void add_lights(Scene& scene)
     auto point = [&scene](vec3 position, vec3 color) { scene.lights.emplace_back(PointLight { position, color }); };
     switch (scene.type) {
     case SingleTriangle:
+        if (scene.meshes.empty()) throw std::runtime_error("triangle.obj holds no mesh");
         scene.meshes[0].material.kd = vec3(1.0f);
         point({ -1, 1, -1 }, vec3(1));
         break;

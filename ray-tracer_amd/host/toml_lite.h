@@ -98,6 +98,7 @@ public:
 private:
     const std::string& m_text;
     size_t m_pos = 0;
+    int m_depth = 0;
     int m_line = 1;
 
     [[noreturn]] void error(const std::string& what) const { throw std::runtime_error("TOML, line " + std::to_string(m_line) + ": " + what); }
@@ -252,8 +253,18 @@ private:
         t->add(path.back()) = std::move(v);
     }
 
+    // arrays and inline tables nest through value(); a hostile file must not exhaust the stack
+    enum { MAX_NESTING = 64 };
+    struct Nesting {
+        int& depth;
+        explicit Nesting(int& d) : depth(d) { depth++; }
+        ~Nesting() { depth--; }
+    };
+
     Value value()
     {
+        const Nesting nesting(m_depth);
+        if (m_depth > MAX_NESTING) error("arrays / inline tables nested deeper than 64 levels");
         const char c = peek();
         Value v;
         if (c == '"') {

@@ -75,6 +75,23 @@ def test_missing_and_unsupported_files_fail_like_the_reference(tmp_path):
     assert res.returncode != 0 and "more than four corners" in res.stderr
 
 
+@pytest.mark.parametrize("body,message", [
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 99\n", "names vertex 99"),                       # index past the end
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nf -1 -2 -7\n", "names vertex"),                        # relative index before the first vertex
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//5\n", "normal that does not exist"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nf 1/1 2/1 3/9\n", "texture coordinate that does not exist"),
+    ("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nf 1 2 3\nf 1 2 4 77\nf 2 3 4\n", None),      # quad with a bad corner is dropped, as tinyobjloader does
+])
+def test_face_indices_outside_the_file_fail_without_reading_out_of_bounds(tmp_path, body, message):
+    f = tmp_path / "broken.obj"
+    f.write_text(body)
+    res = subprocess.run([DRIVER, "--obj", str(f), "0", str(tmp_path / "x")], capture_output=True, text=True, timeout=60)
+    if message is None:
+        assert res.returncode == 0, res.stderr
+    else:
+        assert res.returncode not in (0, -11, -6, 139, 134) and message in res.stderr, (res.returncode, res.stderr)
+
+
 # scene of the golden fixtures -> (file in the reference's data directory, centre and normalise) (reference src/scene.cpp:10-106)
 REFERENCE_SCENES = {
     "single_triangle": ("triangle.obj", 0), "cube_segment": ("cube.obj", 0), "cube_textured": ("cube-textured.obj", 0),
