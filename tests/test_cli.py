@@ -80,7 +80,7 @@ def test_added_keys_and_fallbacks(tmp_path):
     ("a = { b = 1 }\na.c = 2\n", "inline table"),
     ("a = \"\\q\"\n", "unknown escape"),
     ("= 1\n", "expected a key"),
-    ("a = " + "[" * 200000 + "]" * 200000 + "\n", "nested deeper"),  # must be refused, not overflow the stack
+    pytest.param("a = " + "[" * 5000 + "]" * 5000 + "\n", "nested deeper", id="deep-nesting"),  # refused, no stack overflow
 ])
 def test_malformed_toml_is_refused(tmp_path, text, message):
     res = print_config(tmp_path, text)
