@@ -255,6 +255,28 @@ V3 acquireTexel(const Image& img, float u, float v)
     int idx = int(j * float(img.w) + i);
     return img.texel(idx);
 }
+// Bilinear lookup.  The reference declares the switch (common.h:59, enableBilinearTextureFiltering) but its
+// acquireTexel ignores it (texture.cpp:5-17), so there is no reference behaviour to match: PARITY UNPINNED.  Defined
+// here as the natural extension of the nearest lookup: same (1 - v) flip, texel centres at +0.5 (the nearest lookup
+// rounds u*W - 0.5, this one interpolates at u*W - 0.5), repeat wrap, fp32 throughout, blended as
+// (1-fy)*((1-fx)*T00 + fx*T10) + fy*((1-fx)*T01 + fx*T11).
+V3 acquireTexelBilinear(const Image& img, float u, float v)
+{
+    const float x = u * float(img.w) - 0.5f, y = (1 - v) * float(img.h) - 0.5f;
+    const float x0 = std::floor(x), y0 = std::floor(y);
+    const float fx = x - x0, fy = y - y0;
+    auto wrap = [](float c, int n) {
+        float m = std::fmod(c, float(n));
+        if (m < 0) m += float(n);
+        int i = int(m);
+        return i >= n ? n - 1 : i; // m + n can round up to n for a tiny negative m
+    };
+    const int i0 = wrap(x0, img.w), i1 = wrap(x0 + 1.0f, img.w), j0 = wrap(y0, img.h), j1 = wrap(y0 + 1.0f, img.h);
+    const V3 t00 = img.texel(j0 * img.w + i0), t10 = img.texel(j0 * img.w + i1);
+    const V3 t01 = img.texel(j1 * img.w + i0), t11 = img.texel(j1 * img.w + i1);
+    const V3 top = t00 * (1 - fx) + t10 * fx, bottom = t01 * (1 - fx) + t11 * fx;
+    return top * (1 - fy) + bottom * fy;
+}
 // environment_mapping.cpp:44-49
 V3 acquireTexelClamp(const Image& img, float u, float v)
 {
@@ -425,7 +447,8 @@ void applyHitAttributes(const orc_scene& sc, const rt_features& f, const Mesh& m
     if (f.texture_mapping && mesh.material.texture >= 0) {
         float tu = a.u * h.bary.x + b.u * h.bary.y + c.u * h.bary.z; // interpolate.cpp:20-28
         float tv = a.v * h.bary.x + b.v * h.bary.y + c.v * h.bary.z;
-        h.material.kd = acquireTexel(sc.textures[size_t(mesh.material.texture)], tu, tv);
+        const Image& img = sc.textures[size_t(mesh.material.texture)];
+        h.material.kd = f.bilinear_filtering ? acquireTexelBilinear(img, tu, tv) : acquireTexel(img, tu, tv);
     }
     if (f.normal_interp) {
         V3 point = ray.o + ray.d * ray.t;
@@ -1089,6 +1112,13 @@ void orc_kat_interp(const float* in, int32_t n, float* out)
         o[0] = nn.x; o[1] = nn.y; o[2] = nn.z;
         o[3] = a[9] * b.x + a[11] * b.y + a[13] * b.z;
         o[4] = a[10] * b.x + a[12] * b.y + a[14] * b.z;
+    }
+}
+void orc_kat_texel_bilinear(const orc_scene* s, int32_t texture, const float* uv, int32_t n, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        V3 c = acquireTexelBilinear(s->textures[size_t(texture)], uv[2 * i], uv[2 * i + 1]);
+        out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
     }
 }
 void orc_kat_texel(const orc_scene* s, int32_t texture, const float* uv, int32_t n, float* out)

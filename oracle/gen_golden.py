@@ -18,6 +18,8 @@ GOLDEN = os.path.join(HERE, "..", "tests", "golden")
 
 
 def main():
+    # python oracle/gen_golden.py [group ...]: only the named groups (npz files) are rewritten; none = all
+    only = set(sys.argv[1:])
     subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
     with tempfile.TemporaryDirectory() as tmp:
         subprocess.check_call([os.path.join(HERE, "_ref", "ref_dump"), tmp], stdout=subprocess.DEVNULL)
@@ -34,6 +36,8 @@ def main():
         os.makedirs(GOLDEN, exist_ok=True)
         total = 0
         for group, arrays in groups.items():
+            if only and group not in only:
+                continue
             path = os.path.join(GOLDEN, group + ".npz")
             np.savez_compressed(path, **arrays)
             total += os.path.getsize(path)

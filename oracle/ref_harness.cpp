@@ -945,6 +945,33 @@ int main(int argc, char** argv)
             }
             extr_glossy_filterSize = 64;
         }
+        // --- the benchmark configurations' feature sets at fixture size (group "configs" of the golden vectors)
+        if (!big) {
+            // Config 2: textures + sky box on a miss + 2 x 2 supersampling
+            Features f = feat(true, false, false, false, false, true);
+            f.extra.enableEnvironmentMapping = true;
+            f.extra.enableMultipleRaysPerPixel = true;
+            extr_enabledSkyBox = true;
+            RenderOpts o; o.rayMultiplier = 2;
+            rayMultiplier = 2;
+            dump_image("configs." + nm + ".img.A.c2", render_image(scene, bvh, CAM_A, WA, HA, f, o), WA, HA);
+            dump_image("configs." + nm + ".img.B.c2", render_image(scene, bvh, CAM_B, WB, HB, f, o), WB, HB);
+            rayMultiplier = 1;
+            extr_enabledSkyBox = false;
+        }
+        if (nm == "transparent_cornell" || nm == "transparent_cubes") {
+            // Config 4: transparency + glossy reflection with the reference's default 64 samples per bounce,
+            // 2 x 2 supersampling
+            Features f = feat(true, false, false, false, false, false);
+            f.extra.enableGlossyReflection = true;
+            f.extra.enableTransparency = true;
+            f.extra.enableMultipleRaysPerPixel = true;
+            RenderOpts o; o.rayMultiplier = 2;
+            rayMultiplier = 2;
+            extr_glossy_filterSize = 64;
+            dump_image("configs." + nm + ".img.A.c4", render_image(scene, bvh, CAM_A, 48, 32, f, o), 48, 32);
+            rayMultiplier = 1;
+        }
         if (nm == "cornell") {
             // Config 1 at full size: 512x512, shading + recursive + BVH, 1 spp.  Only digests are kept.
             auto full = render_image(scene, bvh, CAM_A, 512, 512, feat(true, true, false, false, false, false), {});

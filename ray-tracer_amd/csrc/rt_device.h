@@ -423,6 +423,30 @@ __device__ __forceinline__ vec3 acquire_texel(const uint8_t* texels, const Image
     return texel_u8(texels, im, int(j * float(im.width) + i));
 }
 
+// Bilinear lookup.  The reference declares the switch (src/common.h:59) but its acquireTexel ignores it
+// (src/texture.cpp:5-17): there is no reference behaviour to match.  Defined as the natural extension of the nearest
+// lookup: same (1 - v) flip, texel centres at +0.5, repeat wrap, fp32 throughout, blended as
+// (1-fy)*((1-fx)*T00 + fx*T10) + fy*((1-fx)*T01 + fx*T11).
+__device__ __forceinline__ int wrap_texel(float c, int n)
+{
+    float m = fmodf(c, float(n));
+    if (m < 0) m += float(n);
+    const int i = int(m);
+    return i >= n ? n - 1 : i; // m + n can round up to n for a tiny negative m
+}
+__device__ __forceinline__ vec3 acquire_texel_bilinear(const uint8_t* texels, const ImageRec& im, float u, float v)
+{
+    const float x = u * float(im.width) - 0.5f, y = (1 - v) * float(im.height) - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    const int i0 = wrap_texel(x0, im.width), i1 = wrap_texel(x0 + 1.0f, im.width);
+    const int j0 = wrap_texel(y0, im.height), j1 = wrap_texel(y0 + 1.0f, im.height);
+    const vec3 t00 = texel_u8(texels, im, j0 * im.width + i0), t10 = texel_u8(texels, im, j0 * im.width + i1);
+    const vec3 t01 = texel_u8(texels, im, j1 * im.width + i0), t11 = texel_u8(texels, im, j1 * im.width + i1);
+    const vec3 top = t00 * (1 - fx) + t10 * fx, bottom = t01 * (1 - fx) + t11 * fx;
+    return top * (1 - fy) + bottom * fy;
+}
+
 // reference src/interpolate.cpp:4-11
 __device__ __forceinline__ vec3 barycentric(vec3 v0, vec3 v1, vec3 v2, vec3 p)
 {
@@ -467,7 +491,8 @@ __device__ __forceinline__ Surface surface_at(const FrameParams& P, const RayD& 
         if (P.f.texture_mapping && m.texture >= 0) {
             const float tu = a.uv0[0] * s.bary.x + a.uv1[0] * s.bary.y + a.uv2[0] * s.bary.z; // interpolate.cpp:20-28
             const float tv = a.uv0[1] * s.bary.x + a.uv1[1] * s.bary.y + a.uv2[1] * s.bary.z;
-            s.kd = acquire_texel(S.texels, S.textures[m.texture], tu, tv);
+            s.kd = P.f.bilinear_filtering ? acquire_texel_bilinear(S.texels, S.textures[m.texture], tu, tv)
+                                          : acquire_texel(S.texels, S.textures[m.texture], tu, tv);
         }
         if (P.f.normal_interp) // interpolate.cpp:13-18
             s.normal = normalize(s.bary.x * load3(a.n0) + s.bary.y * load3(a.n1) + s.bary.z * load3(a.n2));

@@ -43,3 +43,23 @@ GLOSSY_CASES = {
 
 def image_tags(scene):
     return BIG_SCENE_TAGS if scene == "teapot" else list(IMAGE_CASES)
+
+
+# The benchmark configurations' feature sets at fixture size (tests/golden/configs.npz, same generator).
+# key "<scene>.img.<tag>" -> (camera, (W,H), features, params)
+C2_SCENES = [s for s in SCENES if s != "teapot"]
+CONFIG_CASES = {
+    # Config 2: textures + sky box on a miss + 2 x 2 supersampling (nearest texel: what the reference implements)
+    "A.c2": ("A", None, F(shading=1, texture_mapping=1, environment_mapping=1, multiple_rays=1), P(ray_multiplier=2, enabled_skybox=1)),
+    "B.c2": ("B", None, F(shading=1, texture_mapping=1, environment_mapping=1, multiple_rays=1), P(ray_multiplier=2, enabled_skybox=1)),
+    # Config 4: transparency + glossy reflection, 64 samples per bounce (the reference's default), 2 x 2 supersampling
+    "A.c4": ("A", (48, 32), F(shading=1, glossy=1, transparency=1, multiple_rays=1), P(ray_multiplier=2, glossy_filter_size=64)),
+}
+C4_SCENES = ["transparent_cornell", "transparent_cubes"]
+
+
+def psnr(img, ref):
+    """Peak signal-to-noise ratio in dB for frames whose white is 1.0 (inf when identical)."""
+    import numpy as np
+    mse = float(np.mean((np.clip(img, 0, 1).astype(np.float64) - np.clip(ref, 0, 1).astype(np.float64)) ** 2))
+    return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)

@@ -37,6 +37,7 @@ def lib():
         for fn in ("orc_kat_aabb", "orc_kat_tri", "orc_kat_shade", "orc_kat_env", "orc_kat_interp"):
             getattr(l, fn).argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         l.orc_kat_texel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+        l.orc_kat_texel_bilinear.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         l.orc_kat_clamp.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         l.orc_rng_u32.restype = C.c_uint32
         l.orc_rng_u32.argtypes = [C.c_uint32] * 5

@@ -137,6 +137,22 @@ def test_glossy_images(scene):
         assert np.array_equal(img, ref), f"{tag}: max abs diff {np.abs(img - ref).max()}"
 
 
+def _config_cases():
+    return [(s, t) for s in gc.C2_SCENES for t in ("A.c2", "B.c2")] + [(s, "A.c4") for s in gc.C4_SCENES]
+
+
+@pytest.mark.parametrize("scene,tag", _config_cases())
+def test_config_feature_sets_at_fixture_size(scene, tag):
+    """Configs 2 and 4 (sky box + textures + 4 spp; transparency + glossy with 64 samples per bounce + 4 spp) against
+    the compiled reference's frames: bit-identical."""
+    g, sc, orc = scene_and_oracle(scene)
+    which, size, feats, params = gc.CONFIG_CASES[tag]
+    W, H = size or size_of(which)
+    img, _ = orc.render(cam(which, (W, H)), feats, params, W, H)
+    ref = o.golden("configs")[f"{scene}.img.{tag}"]
+    assert np.array_equal(img, ref), f"max abs diff {np.abs(img - ref).max()}"
+
+
 def test_config1_full_size_digest():
     """Config 1 (Cornell 512x512, shading + mirror recursion depth 4 + BVH, 1 spp): bit-identical frame."""
     g, sc, orc = scene_and_oracle("cornell")
@@ -191,3 +207,39 @@ def test_texture_fetch_known_answers():
     out = np.zeros((len(uvf), 3), np.float32)
     o.lib().orc_kat_clamp(orc.h, uvf.ctypes.data, len(uvf), out.ctypes.data)
     assert np.array_equal(out, k["clamp_out"])
+
+
+def test_bilinear_texture_lookup_definition():
+    """Bilinear filtering has no reference behaviour (the reference's acquireTexel ignores its switch): PARITY UNPINNED.
+    The oracle's definition is checked against an independent numpy statement of it and against the nearest lookup
+    at the texel centres, where the two must agree."""
+    g, sc, orc = scene_and_oracle("cube_textured")
+    tex = sc.textures[0]
+    th, tw = tex.shape[0], tex.shape[1]
+    flat = tex.reshape(-1, 3).astype(np.float32) / np.float32(255.0)
+    rng = np.random.default_rng(11)
+    uv = rng.random((4000, 2), dtype=np.float32) * np.float32(1.5) - np.float32(0.25)  # also outside [0, 1): wraps
+    uv[:8] = [[0, 0], [1, 1], [0, 1], [1, 0], [0.5, 0.5], [0.999999, 1e-7], [-0.25, 1.25], [1.0 / tw, 1.0 / th]]
+    out = np.zeros((len(uv), 3), np.float32)
+    o.lib().orc_kat_texel_bilinear(orc.h, 0, uv.ctypes.data, len(uv), out.ctypes.data)
+    f32 = np.float32
+    x = uv[:, 0] * f32(tw) - f32(0.5)
+    y = (f32(1) - uv[:, 1]) * f32(th) - f32(0.5)
+    x0, y0 = np.floor(x), np.floor(y)
+    fx, fy = (x - x0).astype(f32), (y - y0).astype(f32)
+    def wrap(c, n):
+        return np.minimum(np.mod(c.astype(np.int64), n), n - 1)
+    i0, i1, j0, j1 = wrap(x0, tw), wrap(x0 + 1, tw), wrap(y0, th), wrap(y0 + 1, th)
+    t = lambda j, i: flat[j * tw + i]
+    top = t(j0, i0) * (f32(1) - fx)[:, None] + t(j0, i1) * fx[:, None]
+    bottom = t(j1, i0) * (f32(1) - fx)[:, None] + t(j1, i1) * fx[:, None]
+    want = top * (f32(1) - fy)[:, None] + bottom * fy[:, None]
+    assert np.array_equal(out, want.astype(f32))
+    # texel centres: weights are exactly (1, 0), so the result is the nearest lookup's texel
+    ci, cj = np.meshgrid(np.arange(tw), np.arange(th))
+    centres = np.stack([(ci.ravel() + 0.5) / tw, 1.0 - (cj.ravel() + 0.5) / th], axis=1).astype(f32)
+    a = np.zeros((len(centres), 3), f32)
+    b = np.zeros((len(centres), 3), f32)
+    o.lib().orc_kat_texel_bilinear(orc.h, 0, centres.ctypes.data, len(centres), a.ctypes.data)
+    o.lib().orc_kat_texel(orc.h, 0, centres.ctypes.data, len(centres), b.ctypes.data)
+    assert np.array_equal(a, b)
