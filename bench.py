@@ -33,6 +33,10 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak
+L2_PEAK_GBS = 34500.0      # MI355X aggregate L2 bandwidth (8 XCDs)
+CPU_ROW_STEP = 12          # the CPU leg renders every 12th row of the frame
+# the kernels of one frame of the headline workload as rocprofv3 names them (timed variants: test counting off)
+FRAME_KERNELS = ["k_primary<true, false>", "k_stream<false, true>", "k_closest<true, false>", "k_cull", "k_stream<false, false>", "k_shade", "k_resolve"]
 CAMERA = dict(fov_deg=50.0, distance=3.0, look_at=(0.0, 0.0, 0.0), rot_deg=(20.0, 20.0, 0.0))  # reference src/config.h:16-21
 
 
@@ -55,7 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--mesh-level", type=int, default=6, help="icosphere subdivisions: 6 = 81,920 triangles, 8 = 1,310,720")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (the roofline numerator then falls back to the kernel's own test counts)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra 1.31 M-triangle measurement")
     args = ap.parse_args()
 
     import torch
@@ -153,28 +158,53 @@ def main():
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed, rays, traced = float(tmax[0]), int(tsum[1]), int(tsum[2])
 
-    # one untimed frame with test counting on, for the roofline numerator (counts are deterministic)
+    # one untimed frame with test counting on: the tests the kernels themselves perform (counts are deterministic)
     count_params = rt.default_params(ray_multiplier=4, count_tests=1)
     cst = render_frame(count_params)
     torch.cuda.synchronize()
     my_pixels = WIDTH * sum(tiling.block_rows(b, HEIGHT)[1] - tiling.block_rows(b, HEIGHT)[0] for b in my_blocks)
-    # The dominant kernel is the shadow pass, k_stream<COUNT=false, PRIMARY=false>.  Its algorithmic bytes per launch:
-    # 28 B ray in + 16 B result out per shadow ray, 32 B per ray/box test and 36 B per ray/triangle test it performs.  Its launch
-    # duration comes from HIP events recorded on the launch stream around it inside rt_render.
-    all_bytes = algorithmic_bytes(cst, my_pixels)
-    all_flops = algorithmic_flops(cst)
     have_split = shadow_ms > 0.0
-    if have_split:
-        dom_name = "k_stream<false, false> (shadow pass)"
-        dom_bytes = 44 * cst.shadow_rays + 32 * cst.shadow_box_tests + 36 * cst.shadow_triangle_tests
-        dom_flops = 27 * cst.shadow_box_tests + 150 * cst.shadow_triangle_tests
-        dom_s = shadow_ms / args.steps / 1e3
-    else:
-        dom_name = "all kernels of rt_render"
-        dom_bytes, dom_flops, dom_s = all_bytes, all_flops, kernel_ms / args.steps / 1e3
     avg_kernel_s = kernel_ms / args.steps / 1e3
+    dom_s = (shadow_ms if have_split else kernel_ms) / args.steps / 1e3
 
     if rank == 0:
+        # CPU leg (rank 0 only): the oracle on every 12th row of the same frame.  It is the CPU baseline, and its
+        # counters are the ALGORITHM's ray/box and ray/triangle tests in the reference's traversal order (every shadow
+        # query traced as a closest-hit query, none skipped), which is what the roofline numerator is made of.
+        cpu = None if args.no_cpu_baseline else cpu_baseline(rt, scene, cam, feats, params)
+        share = my_pixels / float(WIDTH * HEIGHT)  # rank 0's part of the frame (interleaved blocks: a fair sample)
+        if cpu is not None:
+            ost = cpu.pop("_stats")
+            lit = cpu.pop("_lit")
+            scale = cpu.pop("_scale") * share
+            # the shadow pass processes the queries whose light sample the surface faces (the others are answered by
+            # the cull pass): its numerator is the oracle's tests on exactly those queries, in the reference's order
+            ref_counts = {"source": "oracle (reference traversal order, each query a closest-hit query as in the reference), every "
+                                    f"{CPU_ROW_STEP}th row scaled to " + ("the frame" if world == 1 else "rank 0's share of the frame"),
+                          "shadow_rays": lit[0] * scale, "shadow_box_tests": lit[1] * scale, "shadow_triangle_tests": lit[2] * scale,
+                          "all_shadow_rays": ost.shadow_rays * scale, "all_shadow_box_tests": ost.shadow_box_tests * scale,
+                          "all_shadow_triangle_tests": ost.shadow_triangle_tests * scale, "box_tests": ost.box_tests * scale,
+                          "triangle_tests": ost.triangle_tests * scale, "rays": ost.total_rays() * scale}
+        else:
+            ref_counts = {"source": "the kernels' own test counts (CPU leg skipped)", "shadow_rays": cst.shadow_rays,
+                          "shadow_box_tests": cst.shadow_box_tests, "shadow_triangle_tests": cst.shadow_triangle_tests,
+                          "box_tests": cst.box_tests, "triangle_tests": cst.triangle_tests, "rays": cst.total_rays()}
+        if have_split:
+            dom_name = "k_stream<false, false> (shadow pass)"
+            dom_key = "k_stream<false, false>"
+            alg_flops = 27 * ref_counts["shadow_box_tests"] + 150 * ref_counts["shadow_triangle_tests"]
+            alg_bytes = 44 * ref_counts["shadow_rays"] + 32 * ref_counts["shadow_box_tests"] + 36 * ref_counts["shadow_triangle_tests"]
+            own_flops = 27 * cst.shadow_box_tests + 150 * cst.shadow_triangle_tests
+            own_bytes = 44 * cst.shadow_rays + 32 * cst.shadow_box_tests + 36 * cst.shadow_triangle_tests
+        else:
+            dom_name, dom_key = "all kernels of rt_render", None
+            alg_flops = 27 * ref_counts["box_tests"] + 150 * ref_counts["triangle_tests"]
+            alg_bytes = 44 * ref_counts["rays"] + 32 * ref_counts["box_tests"] + 36 * ref_counts["triangle_tests"] + 12 * my_pixels
+            own_flops, own_bytes = algorithmic_flops(cst), algorithmic_bytes(cst, my_pixels)
+        counters = measured_counters(world)
+        dom_counters = (counters or {}).get("per_kernel", {}).get(dom_key, {}) if dom_key else {}
+        traffic = dom_counters.get("hbm_bytes_per_launch")
+        l2_req = dom_counters.get("l2_read_requests_per_launch")
         frame_ms = elapsed / args.steps * 1e3
         out = {
             "metric": "Mrays/s, dragon-class mesh 1080p 16spp soft shadows (16 light samples)",
@@ -198,51 +228,76 @@ def main():
                 "reference_rays_per_frame": rays // args.steps,
                 "ray_accounting": "value counts the queries the kernels trace (rays_per_frame).  The reference's algorithm issues "
                                   "reference_rays_per_frame for the same frame: shadow queries whose Phong factor is exactly zero "
-                                  "(surface facing away from the light sample) are answered without a ray here, the image is the same",
+                                  "(surface facing away from the light sample) are answered without a ray here, the image is the same.  "
+                                  "The CPU baseline traces all of them: compare it with reference_workload_mrays_per_s",
                 "partition": "whole frame" if world == 1 else f"interleaved {tiling.ROW_BLOCK}-row blocks over {world} ranks, gather to rank 0",
             },
             "frame_ms": frame_ms,
             "reference_workload_mrays_per_s": rays / elapsed / 1e6,
+            # The dominant kernel against the roofs that can bind it.  Its working set (hierarchy + primitives, about
+            # 10 MB) stays in the caches, so HBM is not its roof (hbm.frac below, from the measured traffic); it is
+            # bound by vector-instruction issue, so the headline fraction is fp32 VALU.  No fraction uses a numerator
+            # other than what its field says.
             "roofline": {
                 "kernel": dom_name,
-                "bound": "hbm",
-                "achieved": dom_bytes / dom_s / 1e9,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": measured_traffic(world),
+                "bound": "valu",
+                "achieved": alg_flops / dom_s / 1e12,
+                "peak": FP32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": alg_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS,
+                "traffic": traffic,
                 "kernel_ms": dom_s * 1e3,
-                "algorithmic_bytes_per_launch": dom_bytes,
-                "note": "the working set (hierarchy + primitives, about 10 MB) is cache resident, so HBM is the nominal "
-                        "denominator only and the fraction can exceed 1; the kernel is bound by VALU issue (about 105 "
-                        "vector instructions per 64 ray/node pairs), see valu and profiles/",
-                "valu": {"achieved": dom_flops / dom_s / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": dom_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS},
+                "numerator": "27 flops per ray/box test + 150 per ray/triangle test (sqrt and divide counted as one each) over the tests of "
+                             "the shadow queries this launch answers (those whose light sample the surface faces); counts from: " + ref_counts["source"],
+                "queries_per_launch": {"oracle": ref_counts["shadow_rays"], "kernel": cst.shadow_rays} if have_split else None,
+                "algorithmic_flops_per_launch": alg_flops,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "reference_workload": None if "all_shadow_box_tests" not in ref_counts or not have_split else {
+                    "note": "the same over ALL shadow queries of the reference's algorithm for this frame, including those the cull pass "
+                            "answers without a ray (not work of this launch; shown for scale only)",
+                    "flops": 27 * ref_counts["all_shadow_box_tests"] + 150 * ref_counts["all_shadow_triangle_tests"]},
+                "own_tests": {"note": "the same with the tests the kernel itself performs (any-hit: it stops a query at its first "
+                                      "accepted triangle, where the reference's closest-hit query goes on)",
+                              "flops_per_launch": own_flops, "bytes_per_launch": own_bytes,
+                              "achieved": own_flops / dom_s / 1e12, "frac": own_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS},
+                "hbm": None if traffic is None else {"achieved": traffic / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                     "frac": traffic / dom_s / 1e9 / HBM_PEAK_GBS, "source": "FETCH_SIZE / WRITE_SIZE passes, profiles/traffic.json"},
+                "l2": None if l2_req is None else {"read_requests_per_launch": l2_req, "achieved_at_64B": l2_req * 64 / dom_s / 1e9,
+                                                   "achieved_at_128B": l2_req * 128 / dom_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                                                   "frac_at_64B": l2_req * 64 / dom_s / 1e9 / L2_PEAK_GBS,
+                                                   "frac_at_128B": l2_req * 128 / dom_s / 1e9 / L2_PEAK_GBS,
+                                                   "source": "TCP_TCC_READ_REQ_sum, profiles/traffic.json"},
+                "active_lane_frac": None if counters is None else {k: round(counters["per_kernel"][k]["active_lane_frac"], 3) for k in FRAME_KERNELS
+                                                                   if "active_lane_frac" in counters["per_kernel"].get(k, {})},
+                "counters_from": None if counters is None else counters.get("source"),
                 "all_kernels": {"kernel_ms": avg_kernel_s * 1e3, "primary_ms": primary_ms / args.steps, "shadow_ms": shadow_ms / args.steps,
-                                "cull_ms": cull_ms / args.steps, "shade_ms": shade_ms / args.steps, "algorithmic_bytes": all_bytes,
-                                "achieved_GBps": all_bytes / avg_kernel_s / 1e9, "achieved_TFLOPs": all_flops / avg_kernel_s / 1e12},
+                                "cull_ms": cull_ms / args.steps, "shade_ms": shade_ms / args.steps,
+                                "own_tests_bytes": algorithmic_bytes(cst, my_pixels), "own_tests_flops": algorithmic_flops(cst)},
                 "box_tests_per_ray": cst.box_tests / max(1, cst.total_rays()),
                 "triangle_tests_per_ray": cst.triangle_tests / max(1, cst.total_rays()),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(rt, scene, cam, feats, params)
+        if cpu is not None and world == 1:
+            out["cpu_baseline"] = cpu
+        if world == 1 and not args.no_extra:
+            out["extra"] = {"mesh_level_8": extra_large_mesh(rt, synth, lib, cam, feats, params, local, stream)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def measured_traffic(world):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, in KiB, FETCH_SIZE doubled as
-    prescribed for gfx950), or None when no measurement of the current kernels is committed."""
+def measured_counters(world):
+    """Per-kernel hardware counters from the committed rocprofv3 PMC passes of this same command at one GPU
+    (profiles/traffic.json, written by profiles/make_traffic.py: FETCH_SIZE and WRITE_SIZE collected in separate runs,
+    in KiB, FETCH_SIZE doubled as prescribed for gfx950; L2 read requests; active-lane fraction), or None when no
+    measurement is committed.  They describe a whole-frame launch, so they are only attached at one GPU."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     if world != 1 or not os.path.exists(path):
         return None
     try:
         with open(path) as f:
-            return json.load(f).get("dominant_kernel_hbm_bytes_per_launch")
+            return json.load(f)
     except (OSError, ValueError):
         return None
 
@@ -255,18 +310,41 @@ def cpu_baseline(rt, scene, cam, feats, params):
 
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     osc = o.OracleScene(scene)
-    row_step = 12
     t0 = time.perf_counter()
-    _, st = osc.render(cam, feats, params, WIDTH, HEIGHT, row_step=row_step, threads=threads)
+    _, st = osc.render(cam, feats, params, WIDTH, HEIGHT, row_step=CPU_ROW_STEP, threads=threads)
     dt = time.perf_counter() - t0
+    lit = o.last_lit_shadow_counts()
+    rows = (HEIGHT + CPU_ROW_STEP - 1) // CPU_ROW_STEP
     return {
         "value": st.total_rays() / dt / 1e6,
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"every {row_step}th row of the same 1920x1080 frame at 16 spp ({st.total_rays()} rays, {dt:.1f} s, OpenMP schedule(guided) over rows)",
-        "frame_ms_extrapolated": dt * row_step * 1e3,
+        "sample": f"every {CPU_ROW_STEP}th row ({rows} rows) of the same 1920x1080 frame at 16 spp ({st.total_rays()} rays, {dt:.1f} s, OpenMP schedule(guided) over rows)",
+        "frame_ms_extrapolated": dt * HEIGHT / rows * 1e3,
+        "compare_with": "reference_workload_mrays_per_s (the CPU leg traces every shadow query of the reference's algorithm)",
+        "_stats": st,
+        "_lit": lit,
+        "_scale": HEIGHT / float(rows),
     }
+
+
+def extra_large_mesh(rt, synth, lib, cam, feats, params, out, stream):
+    """The same frame on the 1,310,720-triangle mesh (hierarchy and primitives no longer fit the L2 caches)."""
+    mesh = synth.dragon_class_mesh(8)
+    scene = rt.SceneData([mesh], lights=synth.area_light())
+    t0 = time.perf_counter()
+    bvh = lib.bvh_build(lib.scene_create(scene))
+    build_s = time.perf_counter() - t0
+    lights, n_lights = scene.light_array()
+    best, st = None, None
+    for _ in range(4):
+        _, st = lib.render(bvh, cam, lights, n_lights, feats, params, WIDTH, HEIGHT, 0, HEIGHT, out=out.data_ptr(), device_ptr=1, stream=stream)
+        best = st.kernel_ms + st.resolve_ms if best is None else min(best, st.kernel_ms + st.resolve_ms)
+    return {"triangles": scene.n_triangles, "bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)), "host_build_s": build_s,
+            "frame_ms": best, "mrays_per_s": st.total_rays() / best / 1e3, "reference_workload_mrays_per_s": st.reference_rays() / best / 1e3,
+            "primary_ms": st.primary_ms, "cull_ms": st.cull_ms, "shadow_ms": st.shadow_ms, "shade_ms": st.shade_ms,
+            "note": "device time of rt_render (HIP events), best of 4"}
 
 
 if __name__ == "__main__":

@@ -103,9 +103,15 @@ struct Prim {
 
 struct Counters {
     uint64_t primary = 0, shadow = 0, bounce = 0, probe = 0, box = 0, tri = 0, overflow = 0;
+    uint64_t shadowBox = 0, shadowTri = 0; // the part of box / tri spent inside shadow queries
+    // ... and the part of those spent on queries whose light sample the surface faces (Phong factor not exactly zero):
+    // the only shadow queries whose outcome can reach the pixel
+    uint64_t litShadow = 0, litShadowBox = 0, litShadowTri = 0;
     void add(const Counters& o)
     {
         primary += o.primary; shadow += o.shadow; bounce += o.bounce; probe += o.probe; box += o.box; tri += o.tri; overflow += o.overflow;
+        shadowBox += o.shadowBox; shadowTri += o.shadowTri;
+        litShadow += o.litShadow; litShadowBox += o.litShadowBox; litShadowTri += o.litShadowTri;
     }
 };
 
@@ -612,7 +618,18 @@ float testVisibility(Ctx& C, V3 samplePos, const Ray& ray, const HitInfo& h)
         Ray light { P, samplePos - P, 1.0f };
         HitInfo copy = h;
         C.cnt.shadow++;
-        if (intersectScene(C.sc, light, copy, C.f, C.cnt))
+        const uint64_t box0 = C.cnt.box, tri0 = C.cnt.tri;
+        const bool blocked = intersectScene(C.sc, light, copy, C.f, C.cnt);
+        C.cnt.shadowBox += C.cnt.box - box0;
+        C.cnt.shadowTri += C.cnt.tri - tri0;
+        // bookkeeping only: does the surface face this light sample (the test computeShading makes, shading.cpp:14-21)
+        const V3 point = ray.o + (ray.d * ray.t);
+        if (!C.f.shading || dot(normalize(h.normal), normalize(samplePos - point)) > 0) {
+            C.cnt.litShadow++;
+            C.cnt.litShadowBox += C.cnt.box - box0;
+            C.cnt.litShadowTri += C.cnt.tri - tri0;
+        }
+        if (blocked)
             return 0.0f;
     }
     return 1.0f;
@@ -1023,6 +1040,7 @@ void orc_camera_rays(const rt_camera* c, int32_t W, int32_t H, rt_ray* out)
 // Rows [row_begin,row_end) from the bottom, every row_step-th row only (row_step > 1 is used by the CPU
 // baseline to bound its run time; skipped rows are left untouched).  `out` is the full-frame-sized slice
 // for those rows: (row_end-row_begin)*W pixels, top-most row first.  threads <= 0 keeps OpenMP's default.
+static uint64_t g_lastLit[3] = { 0, 0, 0 };
 void orc_render(const orc_scene* s, const rt_camera* c, const rt_light* lights, int32_t nLights, const rt_features* f, const rt_params* p,
     int32_t W, int32_t H, int32_t rowBegin, int32_t rowEnd, int32_t rowStep, int32_t threads, float* out, rt_stats* stats)
 {
@@ -1054,7 +1072,16 @@ void orc_render(const orc_scene* s, const rt_camera* c, const rt_light* lights, 
         std::memset(stats, 0, sizeof *stats);
         stats->primary_rays = total.primary; stats->shadow_rays = total.shadow; stats->bounce_rays = total.bounce; stats->probe_rays = total.probe;
         stats->box_tests = total.box; stats->triangle_tests = total.tri; stats->transparency_overflows = total.overflow;
+        stats->shadow_box_tests = total.shadowBox; stats->shadow_triangle_tests = total.shadowTri;
     }
+    g_lastLit[0] = total.litShadow; g_lastLit[1] = total.litShadowBox; g_lastLit[2] = total.litShadowTri;
+}
+
+// Counters of the last orc_render call of this process for the shadow queries whose light sample the surface faces:
+// number of queries, their ray/box tests, their ray/triangle tests.
+void orc_last_lit_shadow_counts(uint64_t out[3])
+{
+    for (int i = 0; i < 3; i++) out[i] = g_lastLit[i];
 }
 
 void orc_bloom(float* pixels, int32_t W, int32_t H, const rt_params* p) { addBloom(pixels, W, H, *p); }

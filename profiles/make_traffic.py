@@ -24,10 +24,29 @@ def grab(section, counter):
 fetch, write = grab("fetch", "FETCH_SIZE"), grab("write", "WRITE_SIZE")
 per_kernel = {k: {"fetch_KiB": fetch[k], "write_KiB": write.get(k, 0.0),
                   "hbm_bytes_per_launch": int(2 * fetch[k] * 1024 + write.get(k, 0.0) * 1024)} for k in fetch}
+# L2 read requests (per-CU cache -> L2), and the share of lanes that are active in the vector instructions a kernel
+# issues: SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)
+l2req = grab("tcc", "TCP_TCC_READ_REQ_sum")
+l1acc = grab("tcc", "TCP_TOTAL_CACHE_ACCESSES_sum")
+thread_cycles, active_valu = grab("sq2", "SQ_THREAD_CYCLES_VALU"), grab("sq1", "SQ_ACTIVE_INST_VALU")
+insts_valu, insts_salu, insts_lds = grab("sq1", "SQ_INSTS_VALU"), grab("sq2", "SQ_INSTS_SALU"), grab("sq2", "SQ_INSTS_LDS")
+lds_conflict, lds_active = grab("sq2", "SQ_LDS_BANK_CONFLICT"), grab("sq2", "SQ_ACTIVE_INST_LDS")
+for k in per_kernel:
+    if k in l2req:
+        per_kernel[k]["l2_read_requests_per_launch"] = l2req[k]
+        per_kernel[k]["l1_accesses_per_launch"] = l1acc.get(k)
+    if k in thread_cycles and active_valu.get(k):
+        per_kernel[k]["active_lane_frac"] = thread_cycles[k] / (64.0 * active_valu[k])
+    for name, table in (("valu_insts_per_launch", insts_valu), ("salu_insts_per_launch", insts_salu), ("lds_insts_per_launch", insts_lds),
+                        ("lds_bank_conflict_cycles", lds_conflict), ("lds_active_cycles", lds_active)):
+        if k in table:
+            per_kernel[k][name] = table[k]
 frame = ["k_primary<true, false>", "k_stream<false, true>", "k_closest<true, false>", "k_cull", "k_stream<false, false>", "k_shade", "k_resolve"]
 doc = {
     "source": "profiles/%s/summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, of `python3 bench.py "
               "--steps 3 --warmup 1 --no-cpu-baseline` on one MI355X; per-dispatch averages" % tag,
+    "counters": "l2_read_requests = TCP_TCC_READ_REQ_sum (requests of 64 or 128 bytes); active_lane_frac = "
+                "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); instruction counts are wave instructions",
     "units": "FETCH_SIZE and WRITE_SIZE are reported in KiB; bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-byte read "
              "requests as 64 bytes) + WRITE_SIZE x 1024",
     "per_kernel": per_kernel,

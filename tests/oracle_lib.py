@@ -34,6 +34,7 @@ def lib():
         l.orc_render.argtypes = [C.c_void_p, C.POINTER(capi.Camera), C.POINTER(capi.Light), C.c_int32, C.POINTER(capi.Features), C.POINTER(capi.Params),
                                  C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(capi.Stats)]
         l.orc_bloom.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(capi.Params)]
+        l.orc_last_lit_shadow_counts.argtypes = [C.POINTER(C.c_uint64 * 3)]
         for fn in ("orc_kat_aabb", "orc_kat_tri", "orc_kat_shade", "orc_kat_env", "orc_kat_interp"):
             getattr(l, fn).argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         l.orc_kat_texel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
@@ -97,6 +98,13 @@ def camera_rays(camera, width, height):
     rays = np.zeros(width * height, capi.RAY_DTYPE)
     lib().orc_camera_rays(C.byref(camera), width, height, rays.ctypes.data)
     return rays
+
+
+def last_lit_shadow_counts():
+    """(queries, ray/box tests, ray/triangle tests) of the last render's shadow queries whose light sample the surface faces."""
+    out = (C.c_uint64 * 3)()
+    lib().orc_last_lit_shadow_counts(C.byref(out))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def bloom(image, params):
