@@ -9,7 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "librt_amd.so")
+    """The in-tree build; RT_AMD_LIBRARY names another build of the same library (kernel experiments)."""
+    return os.environ.get("RT_AMD_LIBRARY") or os.path.join(_HERE, "csrc", "librt_amd.so")
 
 
 class ImageDesc(C.Structure):

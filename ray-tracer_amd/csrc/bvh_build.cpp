@@ -339,8 +339,10 @@ void flatten_bvh(const HostScene& scene, const HostBvh& bvh, FlatBvh& out)
         NodeRec& d = out.nodes[size_t(innerIndex[i])];
         const rt_node_record& L = bvh.nodes[size_t(r.a)];
         const rt_node_record& R = bvh.nodes[size_t(r.b)];
-        std::memcpy(d.loL, L.lower, 12); std::memcpy(d.hiL, L.upper, 12);
-        std::memcpy(d.loR, R.lower, 12); std::memcpy(d.hiR, R.upper, 12);
+        for (int ax = 0; ax < 3; ax++) {
+            d.boxL[2 * ax] = L.lower[ax]; d.boxL[2 * ax + 1] = L.upper[ax];
+            d.boxR[2 * ax] = R.lower[ax]; d.boxR[2 * ax + 1] = R.upper[ax];
+        }
         d.refL = refOf(r.a);
         d.refR = refOf(r.b);
         d.level = r.level;

@@ -614,7 +614,7 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     {
         static const int pairStackLds = [] {
             const char* e = std::getenv("RT_PAIR_STACK_LDS"); // tuning / test knob; default chosen by measurement
-            const int v = e ? std::atoi(e) : 512;
+            const int v = e ? std::atoi(e) : 384;
             return v < 64 ? 64 : v;
         }();
         P.pairStackLds = pairStackLds;

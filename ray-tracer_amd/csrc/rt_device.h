@@ -162,8 +162,9 @@ __device__ __forceinline__ bool box_entry(const RayD& r, const float* lo, const 
     return box_entry(r, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], tBox);
 }
 // the two child boxes of a node record loaded with load_rec (field order of NodeRec)
-__device__ __forceinline__ bool box_entry_left(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.a.x, n.a.y, n.a.z, n.a.w, n.b.x, n.b.y, t); }
-__device__ __forceinline__ bool box_entry_right(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.b.z, n.b.w, n.c.x, n.c.y, n.c.z, n.c.w, t); }
+// (a child box is stored lo.x hi.x lo.y hi.y lo.z hi.z)
+__device__ __forceinline__ bool box_entry_left(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.a.x, n.a.z, n.b.x, n.a.y, n.a.w, n.b.y, t); }
+__device__ __forceinline__ bool box_entry_right(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.b.z, n.c.x, n.c.z, n.b.w, n.c.y, n.c.w, t); }
 __device__ __forceinline__ int32_t node_ref_left(const Rec64& n) { return __float_as_int(n.d.x); }
 __device__ __forceinline__ int32_t node_ref_right(const Rec64& n) { return __float_as_int(n.d.y); }
 

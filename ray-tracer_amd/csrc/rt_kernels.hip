@@ -383,7 +383,8 @@ constexpr int STREAM_STAGE_STRIDE = 1024 + 16;            // bytes between the f
 __host__ __device__ constexpr int stream_stack_entries(int levels) { return STREAM_PER_LEVEL * (levels < 2 ? 1 : levels - 1); }
 __host__ __device__ constexpr size_t stream_lds_bytes(int stackEntriesInLds)
 {
-    return 4 * STREAM_STAGE_STRIDE + size_t(STREAM_RAYS) * 4 + size_t(STREAM_LEAF_CAP) * 4 + size_t(stackEntriesInLds) * 4;
+    // record stage, ray table (origin + flags, reciprocal direction: 2 x 16 bytes per ray), leaf pool, pair stack
+    return 4 * STREAM_STAGE_STRIDE + size_t(STREAM_RAYS) * 32 + size_t(STREAM_LEAF_CAP) * 4 + size_t(stackEntriesInLds) * 4;
 }
 constexpr uint32_t STREAM_MAX_WAVES = 256u * 32u; // every wave slot of the chip
 
@@ -437,21 +438,22 @@ __device__ __forceinline__ void lds_fence()
 
 
 // "entered at all" of both child boxes of a node for a ray none of whose direction components is in the
-// zero class: box_entry() followed by the caller's `t < FLT_MAX`, with the twelve plane parameters computed
-// as packed pairs.  o01 = (ox, oy), o20 = (oz, ox), o12 = (oy, oz), likewise the reciprocals: the pairing of
-// the twelve consecutive floats lo.xyz hi.xyz lo.xyz hi.xyz of a node record.
-__device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, f32x2 o01, f32x2 o20, f32x2 o12, f32x2 i01, f32x2 i20, f32x2 i12, bool& left, bool& right)
+// zero class: box_entry() followed by the caller's `t < FLT_MAX`.  a, b, c are the twelve consecutive floats of a
+// node record (two boxes, slab by slab): each slab is one packed subtract and one packed multiply with the ray's
+// origin component and reciprocal broadcast to both halves.
+__device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, float ox, float oy, float oz, float ix, float iy, float iz, bool& left, bool& right)
 {
-    const f32x2 p0 = (a.xy - o01) * i01; // left  lo.x lo.y
-    const f32x2 p1 = (a.zw - o20) * i20; // left  lo.z hi.x
-    const f32x2 p2 = (b.xy - o12) * i12; // left  hi.y hi.z
-    const f32x2 p3 = (b.zw - o01) * i01; // right lo.x lo.y
-    const f32x2 p4 = (c.xy - o20) * i20; // right lo.z hi.x
-    const f32x2 p5 = (c.zw - o12) * i12; // right hi.y hi.z
-    const float tinL = fmaxf(fmaxf(fminf(p0.x, p1.y), fminf(p0.y, p2.x)), fminf(p1.x, p2.y));
-    const float toutL = fminf(fminf(fmaxf(p0.x, p1.y), fmaxf(p0.y, p2.x)), fmaxf(p1.x, p2.y));
-    const float tinR = fmaxf(fmaxf(fminf(p3.x, p4.y), fminf(p3.y, p5.x)), fminf(p4.x, p5.y));
-    const float toutR = fminf(fminf(fmaxf(p3.x, p4.y), fmaxf(p3.y, p5.x)), fmaxf(p4.x, p5.y));
+    const f32x2 oX { ox, ox }, oY { oy, oy }, oZ { oz, oz }, iX { ix, ix }, iY { iy, iy }, iZ { iz, iz };
+    const f32x2 p0 = (a.xy - oX) * iX; // left  x slab
+    const f32x2 p1 = (a.zw - oY) * iY; // left  y slab
+    const f32x2 p2 = (b.xy - oZ) * iZ; // left  z slab
+    const f32x2 p3 = (b.zw - oX) * iX; // right x slab
+    const f32x2 p4 = (c.xy - oY) * iY; // right y slab
+    const f32x2 p5 = (c.zw - oZ) * iZ; // right z slab
+    const float tinL = fmaxf(fmaxf(fminf(p0.x, p0.y), fminf(p1.x, p1.y)), fminf(p2.x, p2.y));
+    const float toutL = fminf(fminf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)), fmaxf(p2.x, p2.y));
+    const float tinR = fmaxf(fmaxf(fminf(p3.x, p3.y), fminf(p4.x, p4.y)), fminf(p5.x, p5.y));
+    const float toutR = fminf(fminf(fmaxf(p3.x, p3.y), fmaxf(p4.x, p4.y)), fmaxf(p5.x, p5.y));
     left = !(tinL > toutL) && !(toutL <= 0) && !is_zero(tinL) && (tinL < 0 ? toutL : tinL) < FLT_MAX;
     right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR) && (tinR < 0 ? toutR : tinR) < FLT_MAX;
 }
@@ -465,13 +467,19 @@ __device__ __forceinline__ float lane_value(uint32_t src, float v)
 template <bool COUNT, bool PRIMARY>
 __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
 {
-    // Ray i of the packet lives in the registers of lane i (origin, direction, reciprocal direction); a lane that
-    // works on a pair of ray i fetches them with lane permutes, which need no LDS space.  Only the ray's flag word
-    // (zero-direction classes, "blocked") is in LDS, because other lanes set it.
+    // Ray i of the packet is set up by lane i.  What a box step needs of it (origin, reciprocal direction, flags) goes
+    // to a table in LDS; the direction, which only the rare primitive steps need, stays in lane i's registers and is
+    // fetched from there with lane permutes.
     extern __shared__ f32x4 streamLds[];
     char* stage = reinterpret_cast<char*>(streamLds);
-    uint32_t* flagsOf = reinterpret_cast<uint32_t*>(stage + 4 * STREAM_STAGE_STRIDE);
-    uint32_t* leafPool = flagsOf + STREAM_RAYS;
+    // Ray table: rayO[i] = (origin, flag word), rayI[i] = (reciprocal direction, unused).  A lane that works on a pair
+    // of ray i reads both with one 16-byte LDS read each (lane permutes of the six values cost several times as much
+    // of the LDS pipeline, which is what this kernel runs out of).  The flag word holds the zero-direction classes and
+    // "blocked"; other lanes set the latter with an LDS atomic.
+    f32x4* rayO = reinterpret_cast<f32x4*>(stage + 4 * STREAM_STAGE_STRIDE);
+    f32x4* rayI = rayO + STREAM_RAYS;
+    uint32_t* leafPool = reinterpret_cast<uint32_t*>(rayI + STREAM_RAYS);
+    auto flag_word = [&](uint32_t i) { return reinterpret_cast<uint32_t*>(rayO + i) + 3; };
     const PairStack pool { leafPool + STREAM_LEAF_CAP, P.pairSpill + size_t(blockIdx.x) * P.pairSpillEntries, uint32_t(P.pairStackLds) };
     const int lane = int(threadIdx.x);
     Counts cnt;
@@ -543,7 +551,8 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
             traced = S.numPrims > 0 && box_entry(r, S.rootLo, S.rootHi, tRoot) && tRoot < tBound;
         }
         const uint32_t zeroBits = (r.zx ? 1u : 0u) | (r.zy ? 2u : 0u) | (r.zz ? 4u : 0u);
-        flagsOf[lane] = zeroBits;
+        rayO[lane] = f32x4 { r.o.x, r.o.y, r.o.z, __uint_as_float(zeroBits) };
+        rayI[lane] = f32x4 { r.inv.x, r.inv.y, r.inv.z, 0.0f };
         const unsigned long long m = __builtin_amdgcn_ballot_w64(traced);
         // some ray of the packet has a direction component in the zero class
         const bool zeroClass = __builtin_amdgcn_ballot_w64(traced && zeroBits != 0u) != 0;
@@ -570,55 +579,62 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 } else {
                     if (got) e = pool.get(count + uint32_t(lane));
                 }
-                // the ray's values are fetched before the node loads are issued so that both are in flight together
+                // the ray's values are read before the node loads are issued so that both are in flight together
                 // (an LDS-class operation placed after them would be made to wait for them)
                 const uint32_t rid = e >> STREAM_REF_BITS;
-                const uint32_t flags = flagsOf[rid];
-                const float ox = lane_value(rid, r.o.x), oy = lane_value(rid, r.o.y), oz = lane_value(rid, r.o.z);
-                const float ix = lane_value(rid, r.inv.x), iy = lane_value(rid, r.inv.y), iz = lane_value(rid, r.inv.z);
+                const f32x4 ro = rayO[rid], ri = rayI[rid];
+                const uint32_t flags = __float_as_uint(ro.w);
+                float ox = ro.x, oy = ro.y, oz = ro.z, ix = ri.x, iy = ri.y, iz = ri.z;
                 asm volatile("" ::: "memory");
                 stage_records(S.nodes, (e & STREAM_REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
-                bool vL = false, vR = false;
-                int32_t refL = 0, refR = 0;
-                stage_wait();
-                if (got && !(flags & RAY_BLOCKED)) {
-                    const f32x4 a = staged[0], b = staged[1], c = staged[2];
-                    const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
-                    if (COUNT) cnt.box += 2;
-                    if (!zeroClass) {
-                        boxes_entered(a, b, c, f32x2 { ox, oy }, f32x2 { oz, ox }, f32x2 { oy, oz }, f32x2 { ix, iy }, f32x2 { iz, ix }, f32x2 { iy, iz }, vL, vR);
-                    } else {
-                        RayD q;
-                        q.o = make3(ox, oy, oz);
-                        q.inv = make3(ix, iy, iz);
-                        q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
-                        float tL, tR;
-                        vL = box_entry(q, a.x, a.y, a.z, a.w, b.x, b.y, tL) && tL < FLT_MAX;
-                        vR = box_entry(q, b.z, b.w, c.x, c.y, c.z, c.w, tR) && tR < FLT_MAX;
-                    }
-                    refL = __float_as_int(refs.x);
-                    refR = __float_as_int(refs.y);
+                // the ray values are named as operands of the wait so that their LDS reads are issued ahead of it (both
+                // kinds of operation are then in flight together)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(ix), "+v"(iy), "+v"(iz)::"memory");
+                // Straight-line from here: every lane evaluates the record its quad staged for it (lanes without a pair,
+                // or whose ray is blocked already, staged record 0 or a stale one; their outcome is masked below).
+                const f32x4 a = staged[0], b = staged[1], c = staged[2];
+                const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
+                const bool live = got && !(flags & RAY_BLOCKED);
+                if (COUNT && live) cnt.box += 2;
+                bool vL, vR;
+                if (!zeroClass) {
+                    boxes_entered(a, b, c, ox, oy, oz, ix, iy, iz, vL, vR);
+                } else {
+                    RayD q;
+                    q.o = make3(ox, oy, oz);
+                    q.inv = make3(ix, iy, iz);
+                    q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
+                    float tL, tR;
+                    vL = box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX;
+                    vR = box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX;
                 }
+                // One code per child: the child reference when the box is entered (inner node: >= 0 as a signed number;
+                // leaf: ~slot, above 0x80000000 as an unsigned one), else NO_CHILD = 0x80000000, which is neither.  Every
+                // vote below is then a single comparison of that register.
+                constexpr uint32_t NO_CHILD = 0x80000000u;
+                const uint32_t cL = (vL && live) ? __float_as_uint(refs.x) : NO_CHILD;
+                const uint32_t cR = (vR && live) ? __float_as_uint(refs.y) : NO_CHILD;
                 const uint32_t tag = rid << STREAM_REF_BITS;
                 // children that are inner nodes go back on the stack, those of higher lanes higher
-                const bool iL = vL && refL >= 0, iR = vR && refR >= 0;
+                const bool iL = int32_t(cL) >= 0, iR = int32_t(cR) >= 0;
                 const unsigned long long bL = __builtin_amdgcn_ballot_w64(iL), bR = __builtin_amdgcn_ballot_w64(iR);
                 const uint32_t nL = uint32_t(__popcll(bL)), nR = uint32_t(__popcll(bR));
-                const uint32_t at = count + lanes_below(bL) + lanes_below(bR);
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(bR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bR),
+                    __builtin_amdgcn_mbcnt_hi(uint32_t(bL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bL), count))));
                 if (inLds) {
-                    if (iL) pool.lds[at] = tag | uint32_t(refL);
-                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | uint32_t(refR);
+                    if (iL) pool.lds[at] = tag | cL;
+                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | cR;
                 } else {
-                    if (iL) pool.put(at, tag | uint32_t(refL));
-                    if (iR) pool.put(at + (iL ? 1u : 0u), tag | uint32_t(refR));
+                    if (iL) pool.put(at, tag | cL);
+                    if (iR) pool.put(at + (iL ? 1u : 0u), tag | cR);
                 }
                 count += nL + nR;
                 // children that are leaves: to the primitive pool
-                const bool lL = vL && refL < 0, lR = vR && refR < 0;
+                const bool lL = cL > NO_CHILD, lR = cR > NO_CHILD;
                 const unsigned long long bLL = __builtin_amdgcn_ballot_w64(lL), bLR = __builtin_amdgcn_ballot_w64(lR);
-                if (lL) leafPool[leafCount + lanes_below(bLL)] = tag | uint32_t(~refL);
+                if (lL) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLL), leafCount))] = tag | ~cL;
                 leafCount += uint32_t(__popcll(bLL));
-                if (lR) leafPool[leafCount + lanes_below(bLR)] = tag | uint32_t(~refR);
+                if (lR) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLR), leafCount))] = tag | ~cR;
                 leafCount += uint32_t(__popcll(bLR));
             } else {
                 // primitive step: up to 64 (ray, leaf) pairs
@@ -627,9 +643,10 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 const uint32_t e = got ? leafPool[leafCount - 1u - uint32_t(lane)] : 0u;
                 leafCount -= k;
                 const uint32_t rid = e >> STREAM_REF_BITS;
-                const uint32_t flags = flagsOf[rid];
+                const f32x4 ro = rayO[rid];
+                const uint32_t flags = __float_as_uint(ro.w);
                 RayD q;
-                q.o = make3(lane_value(rid, r.o.x), lane_value(rid, r.o.y), lane_value(rid, r.o.z));
+                q.o = make3(ro.x, ro.y, ro.z);
                 q.d = make3(lane_value(rid, r.d.x), lane_value(rid, r.d.y), lane_value(rid, r.d.z));
                 asm volatile("" ::: "memory");
                 stage_records(S.prims, (e & STREAM_REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
@@ -655,7 +672,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                         if (COUNT) cnt.tri++;
                         float t;
                         if (triangle_hit(q, p, tBound, t)) {
-                            atomicOr(flagsOf + rid, RAY_BLOCKED);
+                            atomicOr(flag_word(rid), RAY_BLOCKED);
                             break;
                         }
                         slot++;
@@ -665,7 +682,7 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
             __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
         }
         // ---- answers
-        const bool found = flagsOf[lane] & RAY_BLOCKED;
+        const bool found = *flag_word(uint32_t(lane)) & RAY_BLOCKED;
         if (!PRIMARY) {
             if (have) P.visibility[work] = found ? 0 : 1;
         } else {

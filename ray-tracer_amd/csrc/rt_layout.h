@@ -19,9 +19,12 @@
 namespace rt {
 
 // child reference: >= 0 -> index into nodes[]; < 0 -> leaf starting at prims[~ref]
+// The six planes of a child box are stored slab by slab: lo.x hi.x lo.y hi.y lo.z hi.z.  The two planes of a slab
+// meet the same ray origin component and reciprocal, so a slab is one packed subtract and one packed multiply with
+// the ray's scalars broadcast to both halves, and its near / far values are the min / max of the two halves.
 struct alignas(64) NodeRec {
-    float loL[3], hiL[3];
-    float loR[3], hiR[3];
+    float boxL[6];
+    float boxR[6];
     int32_t refL, refR;
     int32_t level;   // depth of this inner node in the reference's tree (root = 0)
     int32_t refNode; // index of this node in the reference's node vector
