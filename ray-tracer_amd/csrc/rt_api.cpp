@@ -624,6 +624,12 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             return v < 1 ? 1 : v;
         }();
         P.primaryBudget = primaryBudget;
+        static const int streamGroup = [] {
+            const char* e = std::getenv("RT_STREAM_GROUP"); // tuning / test knob; default chosen by measurement
+            const int v = e ? std::atoi(e) : 2;
+            return (v == 1 || v == 2 || v == 4) ? v : 2;
+        }();
+        P.streamGroup = streamGroup;
     }
 
     int spp = 1;

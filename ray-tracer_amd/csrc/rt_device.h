@@ -67,6 +67,7 @@ struct FrameParams {
     uint32_t* pairSpill;         // [pairSpillWaves][pairSpillEntries] spill area of the pair stacks
     uint32_t pairSpillEntries;
     uint32_t pairSpillWaves;
+    int32_t streamGroup;         // shadow pass: consecutive queries that share a stack entry (1, 2 or 4)
 };
 
 // Device counters of a pass.  Each sits in a 128-byte line of its own: atomics on one line are served one after the

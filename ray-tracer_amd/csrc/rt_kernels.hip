@@ -358,9 +358,19 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // 64: all lanes work as long as 64 pairs exist, however differently long the individual rays' traversals
 // are, and control flow is wave-uniform.  Pairs whose node is a leaf go to a second pool; a step that tests
 // primitives runs when 64 of those have gathered (or nothing else is left), so box tests and primitive tests
-// never share a step.  A lane works for a different ray every step; ray i stays in the registers of lane i and
-// is fetched from there with lane permutes.  A ray that has been blocked gets a flag in LDS, and its remaining
-// pairs are dropped when popped.
+// never share a step.  A lane works for different rays every step; what it needs of them comes from a ray table in
+// LDS.  A ray that has been blocked gets a flag there, and its remaining pairs are dropped when popped.
+//
+// Ray groups (G = 1, 2 or 4).  The queries of a packet are consecutive work items, i.e. mostly light samples of the
+// same hit: rays with one origin and nearly one direction, which enter mostly the same nodes.  A stack entry is
+// therefore (group of G consecutive rays, node, which rays of the group have entered it): ONE popped entry, one
+// staged node record, and G box tests of that record, each ray deciding for itself exactly as it would alone (a ray
+// whose bit is clear is not tested and cannot enter a child).  The step's fixed cost (pop, record fetch through the
+// per-CU cache and LDS, compaction, pushes) is what the kernel is short of, vector arithmetic is not, so sharing
+// an entry among rays saves steps: on the headline frame 35.1 M box steps with G = 1, 24.7 M with G = 2 (1.46 of 2 rays
+// share an entry on average), 18.8 M with G = 4 (2.0 of 4).  The registers the extra rays take cost occupancy,
+// which this latency-bound kernel needs more: G = 2 held to 96 registers is the fastest (8.67 ms against 8.83 ms
+// for G = 1 and 10.7 ms for G = 4).
 //
 // Stack bound.  The top k <= 64 entries are popped, the topmost by lane k-1, the one below it by lane k-2, and so
 // on; the children are pushed in lane order (those of lane 0 lowest).  By induction the tree levels of the
@@ -372,8 +382,15 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // Persistent waves: a wave whose packet has ended takes the next one from a global cursor and stops once
 // the cursor has passed the packet count.
 constexpr int STREAM_RAYS = 64;                           // rays per packet
-constexpr int STREAM_REF_BITS = 25;                       // pair = ray index (7 bits) | node index or primitive slot
-constexpr uint32_t STREAM_REF_MASK = (1u << STREAM_REF_BITS) - 1u;
+// entry = group index (6, 5, 4 bits for G = 1, 2, 4) | entered-mask (G bits) | node index or primitive slot
+template <int G> struct StreamFormat {
+    static constexpr int LOG_G = G == 1 ? 0 : (G == 2 ? 1 : 2);
+    static constexpr int GROUP_BITS = 6 - LOG_G;
+    static constexpr int REF_BITS = 32 - GROUP_BITS - G; // 25, 25, 24
+    static constexpr uint32_t REF_MASK = (1u << REF_BITS) - 1u;
+    static constexpr uint32_t ALL = (1u << G) - 1u;
+};
+__host__ __device__ constexpr uint32_t stream_ref_limit(int group) { return group == 4 ? (1u << 24) - 1u : (1u << 25) - 1u; }
 constexpr int STREAM_PER_LEVEL = 128;                     // stack entries per inner tree level
 constexpr int STREAM_LEAF_CAP = 192;                      // < 64 waiting + 128 from one step
 constexpr uint32_t RAY_BLOCKED = 8u;                      // flag bit next to the three zero-direction bits
@@ -464,12 +481,13 @@ __device__ __forceinline__ float lane_value(uint32_t src, float v)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(v)));
 }
 
-template <bool COUNT, bool PRIMARY>
-__global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
+template <bool COUNT, bool PRIMARY, int G>
+__global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FrameParams P)
 {
     // Ray i of the packet is set up by lane i.  What a box step needs of it (origin, reciprocal direction, flags) goes
     // to a table in LDS; the direction, which only the rare primitive steps need, stays in lane i's registers and is
     // fetched from there with lane permutes.
+    using F = StreamFormat<G>;
     extern __shared__ f32x4 streamLds[];
     char* stage = reinterpret_cast<char*>(streamLds);
     // Ray table: rayO[i] = (origin, flag word), rayI[i] = (reciprocal direction, unused).  A lane that works on a pair
@@ -556,19 +574,27 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
         const unsigned long long m = __builtin_amdgcn_ballot_w64(traced);
         // some ray of the packet has a direction component in the zero class
         const bool zeroClass = __builtin_amdgcn_ballot_w64(traced && zeroBits != 0u) != 0;
+        // one entry per group of G consecutive rays that has a ray past the root gate: (group, those rays, root)
         uint32_t count = 0, leafCount = 0;
-        if (traced) {
-            const uint32_t at = lanes_below(m);
-            if (S.rootRef >= 0) pool.put(at, (uint32_t(lane) << STREAM_REF_BITS) | uint32_t(S.rootRef));
-            else leafPool[at] = (uint32_t(lane) << STREAM_REF_BITS) | uint32_t(~S.rootRef);
+        {
+            const uint32_t myGroup = uint32_t(lane) >> F::LOG_G;
+            const uint32_t groupMask = uint32_t(m >> (myGroup << F::LOG_G)) & F::ALL;
+            const bool leader = (uint32_t(lane) & (uint32_t(G) - 1u)) == 0u && groupMask != 0u;
+            const unsigned long long lm = __builtin_amdgcn_ballot_w64(leader);
+            if (leader) {
+                const uint32_t at = lanes_below(lm);
+                const uint32_t head = (myGroup << (32 - F::GROUP_BITS)) | (groupMask << F::REF_BITS);
+                if (S.rootRef >= 0) pool.put(at, head | uint32_t(S.rootRef));
+                else leafPool[at] = head | uint32_t(~S.rootRef);
+            }
+            if (S.rootRef >= 0) count = uint32_t(__popcll(lm));
+            else leafCount = uint32_t(__popcll(lm));
         }
-        if (S.rootRef >= 0) count = uint32_t(__popcll(m));
-        else leafCount = uint32_t(__popcll(m));
         lds_fence();
         // ---- the stream
         while (count | leafCount) {
             if (count && leafCount < 64u) {
-                // box step: the top 64 pairs
+                // box step: the top 64 entries
                 const uint32_t k = count < 64u ? count : 64u;
                 const bool got = uint32_t(lane) < k;
                 const bool inLds = count - k + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
@@ -579,42 +605,55 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 } else {
                     if (got) e = pool.get(count + uint32_t(lane));
                 }
-                // the ray's values are read before the node loads are issued so that both are in flight together
+                // the rays' values are read before the node loads are issued so that both are in flight together
                 // (an LDS-class operation placed after them would be made to wait for them)
-                const uint32_t rid = e >> STREAM_REF_BITS;
-                const f32x4 ro = rayO[rid], ri = rayI[rid];
-                const uint32_t flags = __float_as_uint(ro.w);
-                float ox = ro.x, oy = ro.y, oz = ro.z, ix = ri.x, iy = ri.y, iz = ri.z;
+                const uint32_t first = (e >> (32 - F::GROUP_BITS)) << F::LOG_G; // first ray of the group
+                const uint32_t mask = got ? (e >> F::REF_BITS) & F::ALL : 0u;
+                f32x4 ro[G], ri[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    ro[g] = rayO[first + uint32_t(g)];
+                    ri[g] = rayI[first + uint32_t(g)];
+                }
                 asm volatile("" ::: "memory");
-                stage_records(S.nodes, (e & STREAM_REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
-                // the ray values are named as operands of the wait so that their LDS reads are issued ahead of it (both
-                // kinds of operation are then in flight together)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ox), "+v"(oy), "+v"(oz), "+v"(ix), "+v"(iy), "+v"(iz)::"memory");
-                // Straight-line from here: every lane evaluates the record its quad staged for it (lanes without a pair,
-                // or whose ray is blocked already, staged record 0 or a stale one; their outcome is masked below).
+                stage_records(S.nodes, (e & F::REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
+                // the ray values are named as operands of the wait so that their LDS reads are issued ahead of it
+                if (G == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0])::"memory");
+                else if (G == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0])::"memory");
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0]), "+v"(ro[G > 2 ? 2 : 0]), "+v"(ri[G > 2 ? 2 : 0]), "+v"(ro[G > 3 ? 3 : 0]), "+v"(ri[G > 3 ? 3 : 0])::"memory");
+                // Straight-line from here: every lane evaluates the record its quad staged for it (lanes without an
+                // entry staged record 0; their outcome is masked).
                 const f32x4 a = staged[0], b = staged[1], c = staged[2];
                 const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
-                const bool live = got && !(flags & RAY_BLOCKED);
-                if (COUNT && live) cnt.box += 2;
-                bool vL, vR;
-                if (!zeroClass) {
-                    boxes_entered(a, b, c, ox, oy, oz, ix, iy, iz, vL, vR);
-                } else {
-                    RayD q;
-                    q.o = make3(ox, oy, oz);
-                    q.inv = make3(ix, iy, iz);
-                    q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
-                    float tL, tR;
-                    vL = box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX;
-                    vR = box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX;
+                uint32_t mL = 0u, mR = 0u; // rays of the group that enter the left / right child
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const uint32_t flags = __float_as_uint(ro[g].w);
+                    const bool live = ((mask >> g) & 1u) && !(flags & RAY_BLOCKED);
+                    if (COUNT && live) cnt.box += 2;
+                    bool vL, vR;
+                    if (!zeroClass) {
+                        boxes_entered(a, b, c, ro[g].x, ro[g].y, ro[g].z, ri[g].x, ri[g].y, ri[g].z, vL, vR);
+                    } else {
+                        RayD q;
+                        q.o = make3(ro[g].x, ro[g].y, ro[g].z);
+                        q.inv = make3(ri[g].x, ri[g].y, ri[g].z);
+                        q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
+                        float tL, tR;
+                        vL = box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX;
+                        vR = box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX;
+                    }
+                    mL |= (vL && live) ? (1u << g) : 0u;
+                    mR |= (vR && live) ? (1u << g) : 0u;
                 }
-                // One code per child: the child reference when the box is entered (inner node: >= 0 as a signed number;
-                // leaf: ~slot, above 0x80000000 as an unsigned one), else NO_CHILD = 0x80000000, which is neither.  Every
-                // vote below is then a single comparison of that register.
+                // One code per child: the child reference when some ray of the group enters the box (inner node: >= 0 as
+                // a signed number; leaf: ~slot, above 0x80000000 as an unsigned one), else NO_CHILD = 0x80000000, which
+                // is neither.  Every vote below is then a single comparison of that register.
                 constexpr uint32_t NO_CHILD = 0x80000000u;
-                const uint32_t cL = (vL && live) ? __float_as_uint(refs.x) : NO_CHILD;
-                const uint32_t cR = (vR && live) ? __float_as_uint(refs.y) : NO_CHILD;
-                const uint32_t tag = rid << STREAM_REF_BITS;
+                const uint32_t cL = mL ? __float_as_uint(refs.x) : NO_CHILD;
+                const uint32_t cR = mR ? __float_as_uint(refs.y) : NO_CHILD;
+                const uint32_t tag = e & ~((1u << (32 - F::GROUP_BITS)) - 1u); // the group index, in place
+                const uint32_t eL = tag | (mL << F::REF_BITS), eR = tag | (mR << F::REF_BITS);
                 // children that are inner nodes go back on the stack, those of higher lanes higher
                 const bool iL = int32_t(cL) >= 0, iR = int32_t(cR) >= 0;
                 const unsigned long long bL = __builtin_amdgcn_ballot_w64(iL), bR = __builtin_amdgcn_ballot_w64(iR);
@@ -622,61 +661,69 @@ __global__ void __launch_bounds__(WAVE) k_stream(const FrameParams P)
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(bR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bR),
                     __builtin_amdgcn_mbcnt_hi(uint32_t(bL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bL), count))));
                 if (inLds) {
-                    if (iL) pool.lds[at] = tag | cL;
-                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | cR;
+                    if (iL) pool.lds[at] = eL | cL;
+                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = eR | cR;
                 } else {
-                    if (iL) pool.put(at, tag | cL);
-                    if (iR) pool.put(at + (iL ? 1u : 0u), tag | cR);
+                    if (iL) pool.put(at, eL | cL);
+                    if (iR) pool.put(at + (iL ? 1u : 0u), eR | cR);
                 }
                 count += nL + nR;
                 // children that are leaves: to the primitive pool
                 const bool lL = cL > NO_CHILD, lR = cR > NO_CHILD;
                 const unsigned long long bLL = __builtin_amdgcn_ballot_w64(lL), bLR = __builtin_amdgcn_ballot_w64(lR);
-                if (lL) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLL), leafCount))] = tag | ~cL;
+                if (lL) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLL), leafCount))] = eL | ~cL;
                 leafCount += uint32_t(__popcll(bLL));
-                if (lR) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLR), leafCount))] = tag | ~cR;
+                if (lR) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLR), leafCount))] = eR | ~cR;
                 leafCount += uint32_t(__popcll(bLR));
             } else {
-                // primitive step: up to 64 (ray, leaf) pairs
+                // primitive step: up to 64 (group, leaf) entries
                 const uint32_t k = leafCount < 64u ? leafCount : 64u;
                 const bool got = uint32_t(lane) < k;
                 const uint32_t e = got ? leafPool[leafCount - 1u - uint32_t(lane)] : 0u;
                 leafCount -= k;
-                const uint32_t rid = e >> STREAM_REF_BITS;
-                const f32x4 ro = rayO[rid];
-                const uint32_t flags = __float_as_uint(ro.w);
-                RayD q;
-                q.o = make3(ro.x, ro.y, ro.z);
-                q.d = make3(lane_value(rid, r.d.x), lane_value(rid, r.d.y), lane_value(rid, r.d.z));
+                const uint32_t first = (e >> (32 - F::GROUP_BITS)) << F::LOG_G;
+                uint32_t mask = got ? (e >> F::REF_BITS) & F::ALL : 0u;
+                RayD q[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const f32x4 o = rayO[first + uint32_t(g)];
+                    q[g].o = make3(o.x, o.y, o.z);
+                    q[g].d = make3(lane_value(first + uint32_t(g), r.d.x), lane_value(first + uint32_t(g), r.d.y), lane_value(first + uint32_t(g), r.d.z));
+                    if (__float_as_uint(o.w) & RAY_BLOCKED) mask &= ~(1u << g);
+                }
                 asm volatile("" ::: "memory");
-                stage_records(S.prims, (e & STREAM_REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
+                stage_records(S.prims, (e & F::REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
                 stage_wait();
-                if (got && !(flags & RAY_BLOCKED)) {
-                    int32_t slot = int32_t(e & STREAM_REF_MASK);
+                if (mask) {
+                    int32_t slot = int32_t(e & F::REF_MASK);
                     int32_t more;
-                    bool first = true;
+                    bool firstRec = true;
                     do {
                         // the leaf's first record is staged; further ones (leaves cut off by the level limit) come one by one
                         Rec64 p;
-                        if (first) {
+                        if (firstRec) {
                             const f32x4 q0 = staged[0], q1 = staged[1], q2 = staged[2], q3 = staged[3];
                             p.a = make_float4(q0.x, q0.y, q0.z, q0.w);
                             p.b = make_float4(q1.x, q1.y, q1.z, q1.w);
                             p.c = make_float4(q2.x, q2.y, q2.z, q2.w);
                             p.d = make_float4(q3.x, q3.y, q3.z, q3.w);
-                            first = false;
+                            firstRec = false;
                         } else {
                             p = load_rec(&S.prims[slot]);
                         }
                         more = prim_more(p);
-                        if (COUNT) cnt.tri++;
-                        float t;
-                        if (triangle_hit(q, p, tBound, t)) {
-                            atomicOr(flag_word(rid), RAY_BLOCKED);
-                            break;
+#pragma unroll
+                        for (int g = 0; g < G; g++) {
+                            if (!((mask >> g) & 1u)) continue;
+                            if (COUNT) cnt.tri++;
+                            float t;
+                            if (triangle_hit(q[g], p, tBound, t)) {
+                                atomicOr(flag_word(first + uint32_t(g)), RAY_BLOCKED);
+                                mask &= ~(1u << g); // this ray is answered
+                            }
                         }
                         slot++;
-                    } while (more > 0);
+                    } while (more > 0 && mask);
                 }
             }
             __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
@@ -916,6 +963,30 @@ hipError_t launch_render_t(const FrameParams& P, size_t lds, hipStream_t stream)
     return hipGetLastError();
 }
 
+// The stream kernel on every resident wave (how many queries there are is only known on the device).
+template <bool COUNT, bool PRIMARY, int G>
+void launch_stream_g(const FrameParams& P, uint32_t wanted, size_t lds, hipStream_t stream)
+{
+    uint32_t cap = resident_blocks(k_stream<COUNT, PRIMARY, G>, WAVE, lds);
+    if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
+    hipLaunchKernelGGL((k_stream<COUNT, PRIMARY, G>), dim3(wanted < cap ? wanted : cap), dim3(WAVE), lds, stream, P);
+}
+template <bool PRIMARY>
+void launch_stream(const FrameParams& P, uint32_t wanted, size_t lds, hipStream_t stream)
+{
+    // camera rays that gave up are unrelated rays: no groups there
+    const int group = PRIMARY ? 1 : P.streamGroup;
+    if (P.countTests) {
+        if (group == 4) launch_stream_g<true, PRIMARY, PRIMARY ? 1 : 4>(P, wanted, lds, stream);
+        else if (group == 2) launch_stream_g<true, PRIMARY, PRIMARY ? 1 : 2>(P, wanted, lds, stream);
+        else launch_stream_g<true, PRIMARY, 1>(P, wanted, lds, stream);
+    } else {
+        if (group == 4) launch_stream_g<false, PRIMARY, PRIMARY ? 1 : 4>(P, wanted, lds, stream);
+        else if (group == 2) launch_stream_g<false, PRIMARY, PRIMARY ? 1 : 2>(P, wanted, lds, stream);
+        else launch_stream_g<false, PRIMARY, 1>(P, wanted, lds, stream);
+    }
+}
+
 template <bool PRUNE>
 hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev)
 {
@@ -933,11 +1004,7 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
         }
         // how many rays gave up, and how many of those meet a primitive, is only known on the device: both kernels
         // get a grid that covers every resident wave
-        uint32_t cap = P.countTests ? resident_blocks(k_stream<true, true>, WAVE, streamLds) : resident_blocks(k_stream<false, true>, WAVE, streamLds);
-        if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
-        const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
-        if (P.countTests) hipLaunchKernelGGL((k_stream<true, true>), g, dim3(WAVE), streamLds, stream, P);
-        else hipLaunchKernelGGL((k_stream<false, true>), g, dim3(WAVE), streamLds, stream, P);
+        launch_stream<true>(P, gridDirect.x, streamLds, stream);
         const uint32_t walkers = P.countTests ? resident_blocks(k_closest<PRUNE, true>, WAVE, lds) : resident_blocks(k_closest<PRUNE, false>, WAVE, lds);
         const dim3 gc(gridDirect.x < walkers ? gridDirect.x : walkers);
         if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, stream, P);
@@ -947,11 +1014,7 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
     if (P.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
     if (ev) (void)hipEventRecord(ev[1], stream);
     if (P.shadowSamplesPerHit > 0) {
-        uint32_t cap = P.countTests ? resident_blocks(k_stream<true, false>, WAVE, streamLds) : resident_blocks(k_stream<false, false>, WAVE, streamLds);
-        if (P.pairSpillEntries > 0 && cap > P.pairSpillWaves) cap = P.pairSpillWaves;
-        const dim3 g(gridDirect.x < cap ? gridDirect.x : cap);
-        if (P.countTests) hipLaunchKernelGGL((k_stream<true, false>), g, dim3(WAVE), streamLds, stream, P);
-        else hipLaunchKernelGGL((k_stream<false, false>), g, dim3(WAVE), streamLds, stream, P);
+        launch_stream<false>(P, gridDirect.x, streamLds, stream);
     }
     if (ev) (void)hipEventRecord(ev[2], stream);
     hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
@@ -987,7 +1050,9 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     const bool prune = !P.f.recursive && !P.f.transparency;
     const bool glossy = P.f.glossy != 0;
     // the shadow pass packs a node index or primitive slot into STREAM_REF_BITS bits (inner nodes are fewer than primitives)
-    const bool fits = uint32_t(P.scene.numPrims) <= STREAM_REF_MASK && P.scene.stackDepth < 64;
+    if (P.streamGroup != 1 && P.streamGroup != 2 && P.streamGroup != 4) P.streamGroup = 2;
+    if (P.streamGroup == 4 && uint32_t(P.scene.numPrims) > stream_ref_limit(4)) P.streamGroup = 2;
+    const bool fits = uint32_t(P.scene.numPrims) <= stream_ref_limit(P.streamGroup) && P.scene.stackDepth < 64;
     const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P) && fits;
     hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
