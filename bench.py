@@ -61,7 +61,14 @@ def main():
     ap.add_argument("--mesh-level", type=int, default=6, help="icosphere subdivisions: 6 = 81,920 triangles, 8 = 1,310,720")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (the roofline numerator then falls back to the kernel's own test counts)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra 1.31 M-triangle measurement")
+    ap.add_argument("--workload", choices=["c3", "c5"], default="c3",
+                    help="c3 (default): the headline workload, BASELINE.json configs[2]; c5: configs[4] in the form the reference can express "
+                         "(3840x2160, soft shadows + depth of field with 63 lens rays + bloom, no supersampling)")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 writes the last assembled frame to this .npy file")
     args = ap.parse_args()
+    global WIDTH, HEIGHT, CPU_ROW_STEP
+    if args.workload == "c5":
+        WIDTH, HEIGHT, CPU_ROW_STEP = 3840, 2160, 96
 
     import torch
     import torch.distributed as dist
@@ -94,8 +101,15 @@ def main():
     bvh = lib.bvh_build(sh)
     lights, n_lights = scene.light_array()
     cam = rt.make_camera(width=WIDTH, height=HEIGHT, **CAMERA)
-    feats = rt.features(shading=1, soft_shadow=1, multiple_rays=1)
-    params = rt.default_params(ray_multiplier=4)
+    if args.workload == "c5":
+        feats = rt.features(shading=1, soft_shadow=1, depth_of_field=1, bloom=1)
+        param_args = dict(dof_samples=63, dof_f=2.5, dof=0.05, dof_aperture=1.4)
+        label = "3840x2160 soft shadows (16 light samples) + depth of field (63 lens rays) + bloom"
+    else:
+        feats = rt.features(shading=1, soft_shadow=1, multiple_rays=1)
+        param_args = dict(ray_multiplier=4)
+        label = "1080p 16spp soft shadows (16 light samples)"
+    params = rt.default_params(**param_args)
 
     # interleaved 16-row blocks, block b belongs to rank b % world (ray-tracer_amd/tiling.py)
     my_blocks = tiling.blocks_of_rank(rank, world, HEIGHT)
@@ -123,10 +137,16 @@ def main():
                 setattr(total, name, getattr(total, name) + getattr(st, name))
         return total
 
+    last = {}
+
     def step():
         st = render_frame(params)
-        if world > 1:
-            tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered, row_index=row_index)
+        frame = tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered, row_index=row_index)
+        if rank == 0:
+            if feats.bloom:  # the whole-frame post pass runs where the frame is assembled (reference src/render.cpp:125-127)
+                frame = frame.contiguous()
+                lib.bloom_device(frame.data_ptr(), WIDTH, HEIGHT, params, stream)
+            last["frame"] = frame
         return st
 
     def barrier():
@@ -159,7 +179,7 @@ def main():
         elapsed, rays, traced = float(tmax[0]), int(tsum[1]), int(tsum[2])
 
     # one untimed frame with test counting on: the tests the kernels themselves perform (counts are deterministic)
-    count_params = rt.default_params(ray_multiplier=4, count_tests=1)
+    count_params = rt.default_params(count_tests=1, **param_args)
     cst = render_frame(count_params)
     torch.cuda.synchronize()
     my_pixels = WIDTH * sum(tiling.block_rows(b, HEIGHT)[1] - tiling.block_rows(b, HEIGHT)[0] for b in my_blocks)
@@ -207,7 +227,7 @@ def main():
         l2_req = dom_counters.get("l2_read_requests_per_launch")
         frame_ms = elapsed / args.steps * 1e3
         out = {
-            "metric": "Mrays/s, dragon-class mesh 1080p 16spp soft shadows (16 light samples)",
+            "metric": "Mrays/s, dragon-class mesh " + label,
             "value": traced / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
@@ -220,8 +240,11 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"configs[2]: dragon-class mesh ({scene.n_triangles} triangles, synthetic stand-in for the absent dragon.obj), "
-                            f"{WIDTH}x{HEIGHT}, BVH on, Phong + parallelogram light soft shadows (16 samples), 16 spp",
+                "workload": (f"configs[2]: dragon-class mesh ({scene.n_triangles} triangles, synthetic stand-in for the absent dragon.obj), "
+                             f"{WIDTH}x{HEIGHT}, BVH on, Phong + parallelogram light soft shadows (16 samples), 16 spp") if args.workload == "c3" else
+                            (f"configs[4] as the reference can express it: dragon-class mesh ({scene.n_triangles} triangles), {WIDTH}x{HEIGHT}, BVH on, Phong + "
+                             "soft shadows (16 samples) + depth of field (centre ray + 63 lens rays where the pixel is out of focus) + bloom on the "
+                             "assembled frame; no supersampling (the reference skips depth of field when it is on), no glossy reflection"),
                 "triangles": scene.n_triangles,
                 "bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)),
                 "rays_per_frame": traced // args.steps,
@@ -279,7 +302,10 @@ def main():
         }
         if cpu is not None and world == 1:
             out["cpu_baseline"] = cpu
-        if world == 1 and not args.no_extra:
+        if args.dump_frame:
+            torch.cuda.synchronize()
+            np.save(args.dump_frame, last["frame"].cpu().numpy())
+        if world == 1 and not args.no_extra and args.workload == "c3":
             out["extra"] = {"mesh_level_8": extra_large_mesh(rt, synth, lib, cam, feats, params, local, stream)}
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -320,7 +346,7 @@ def cpu_baseline(rt, scene, cam, feats, params):
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"every {CPU_ROW_STEP}th row ({rows} rows) of the same 1920x1080 frame at 16 spp ({st.total_rays()} rays, {dt:.1f} s, OpenMP schedule(guided) over rows)",
+        "sample": f"every {CPU_ROW_STEP}th row ({rows} rows) of the same {WIDTH}x{HEIGHT} frame at full sample count ({st.total_rays()} rays, {dt:.1f} s, OpenMP schedule(guided) over rows)",
         "frame_ms_extrapolated": dt * HEIGHT / rows * 1e3,
         "compare_with": "reference_workload_mrays_per_s (the CPU leg traces every shadow query of the reference's algorithm)",
         "_stats": st,

@@ -1,0 +1,85 @@
+"""The N > 1 control flow of bench.py, run as the driver launches it (torch.distributed.run, one process per rank) but on
+ONE GPU: BENCH_ONE_GPU_REHEARSAL=1 makes every rank use GPU 0 and the exchange run on gloo.  What is checked is what
+does not depend on the interconnect: every rank renders its interleaved row blocks with one rt_render_blocks call, the
+gather puts the frame together on rank 0, bloom (a whole-frame pass) runs there after the gather, rank 0 prints one
+JSON line with the roofline block, and the frame is bit-identical to a single-process render.  The RCCL gather itself
+(backend "nccl") needs more than one GPU and is not exercised here."""
+import importlib
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+
+rt = o.rt
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run_bench(world, workload, frame_path, extra=()):
+    env = dict(os.environ, BENCH_ONE_GPU_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(o.ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--workload", workload, "--dump-frame", frame_path, *extra]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=o.ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # rank 0 alone prints, once
+    return json.loads(lines[0])
+
+
+def _single_process_frame(workload):
+    synth = importlib.import_module("ray-tracer_amd.synth")
+    lib = rt.Library()
+    lib.init(0)
+    sc = rt.SceneData([synth.dragon_class_mesh(6)], lights=synth.area_light())
+    bvh = lib.bvh_build(lib.scene_create(sc))
+    lights, n = sc.light_array()
+    if workload == "c5":
+        W, H = 3840, 2160
+        feats = rt.features(shading=1, soft_shadow=1, depth_of_field=1, bloom=1)
+        params = rt.default_params(dof_samples=63, dof_f=2.5, dof=0.05, dof_aperture=1.4)
+    else:
+        W, H = 1920, 1080
+        feats = rt.features(shading=1, soft_shadow=1, multiple_rays=1)
+        params = rt.default_params(ray_multiplier=4)
+    cam = rt.make_camera(width=W, height=H, fov_deg=50.0, distance=3.0, look_at=(0.0, 0.0, 0.0), rot_deg=(20.0, 20.0, 0.0))
+    img, stats = lib.render(bvh, cam, lights, n, feats, params, W, H)
+    if feats.bloom:
+        img = lib.bloom(img, params)
+    return img, stats
+
+
+def test_eight_ranks_headline_workload(tmp_path):
+    frame_path = str(tmp_path / "frame.npy")
+    out = _run_bench(8, "c3", frame_path)
+    assert out["n_gpus"] == 8 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+    roof = out["roofline"]
+    assert roof["bound"] == "valu" and 0 < roof["frac"] <= 1 and 0 < roof["own_tests"]["frac"] <= 1
+    assert "interleaved 16-row blocks over 8 ranks" in out["config"]["partition"]
+    ref, stats = _single_process_frame("c3")
+    assert out["config"]["rays_per_frame"] == stats.total_rays()  # the ranks' shares add up to the whole frame's rays
+    assert out["config"]["reference_rays_per_frame"] == stats.reference_rays()
+    assert np.array_equal(np.load(frame_path), ref)
+
+
+def test_four_ranks_config5_bloom_after_gather(tmp_path):
+    frame_path = str(tmp_path / "frame.npy")
+    out = _run_bench(4, "c5", frame_path, extra=("--no-cpu-baseline",))
+    assert out["n_gpus"] == 4 and "3840x2160" in out["config"]["workload"]
+    ref, stats = _single_process_frame("c5")
+    assert out["config"]["rays_per_frame"] == stats.total_rays()
+    assert np.array_equal(np.load(frame_path), ref)
