@@ -146,6 +146,23 @@ inline uint32_t rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t
 }
 enum { STREAM_RAND = 0, STREAM_DOF = 1, STREAM_GLOSS = 2 };
 inline double u01(uint32_t u) { return (double(u) + 0.5) * (1.0 / 4294967296.0); }
+inline uint32_t floatBits(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+// Key of one glossy-reflection call: a hash of the bits of the reflection ray it perturbs.  Sample i of the call uses
+// the Gaussian deviates key + 2i and key + 2i + 1 of the glossy stream.
+inline uint32_t rayKey6(float ox, float oy, float oz, float dx, float dy, float dz)
+{
+    uint32_t h = hash32(floatBits(ox) ^ 0x9e3779b9U);
+    h = hash32(h ^ floatBits(oy));
+    h = hash32(h ^ floatBits(oz));
+    h = hash32(h ^ floatBits(dx));
+    h = hash32(h ^ floatBits(dy));
+    return hash32(h ^ floatBits(dz));
+}
 
 struct Rng {
     uint32_t seed = 1, pixel = 0, sample = 0, randCounter = 0, glossCall = 0;
@@ -712,9 +729,10 @@ int glossySamples(Ctx& C, const HitInfo& h, const Ray& ref, std::vector<Ray>& ou
     V3 v = cross(w, u);
     float side = C.p.glossy_sigma / (h.material.shininess * 3.0f);
     float offset = -side / 2.0f;
-    uint32_t call = C.rng.glossCall++;
+    // the call's deviates are indexed from a hash of the reflection ray's bits (see rayKey6)
+    uint32_t call = rayKey6(ref.o.x, ref.o.y, ref.o.z, ref.d.x, ref.d.y, ref.d.z);
     for (int i = 0; i < C.p.glossy_filter_size; i++) {
-        uint32_t k = (call * uint32_t(C.p.glossy_filter_size) + uint32_t(i)) * 2u;
+        uint32_t k = call + 2u * uint32_t(i);
         double n0 = C.rng.gauss(k), n1 = C.rng.gauss(k + 1u);
         V3 rPrime = (ref.d + float(double(offset) + n0 * double(side)) * u) + float(double(offset) + n1 * double(side)) * v;
         if (dot(rPrime, h.normal) > 0)

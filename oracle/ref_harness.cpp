@@ -87,6 +87,23 @@ static inline uint32_t rng_u32(uint32_t seed, uint32_t pixel, uint32_t sample, u
     return hash32(h ^ index);
 }
 enum { STREAM_RAND = 0, STREAM_DOF = 1, STREAM_GLOSS = 2 };
+static inline uint32_t float_bits(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+// Key of one getRaySamples call: a hash of the bits of the reflection ray it perturbs.  Sample i of the call uses the
+// Gaussian deviates key + 2i and key + 2i + 1 of the glossy stream (same specification as the oracle and the kernels).
+static inline uint32_t ray_key(const glm::vec3& o, const glm::vec3& d)
+{
+    uint32_t h = hash32(float_bits(o.x) ^ 0x9e3779b9U);
+    h = hash32(h ^ float_bits(o.y));
+    h = hash32(h ^ float_bits(o.z));
+    h = hash32(h ^ float_bits(d.x));
+    h = hash32(h ^ float_bits(d.y));
+    return hash32(h ^ float_bits(d.z));
+}
 
 struct RngCtx {
     uint32_t seed = 1, pixel = 0, sample = 0;
@@ -180,9 +197,10 @@ std::vector<Ray> getRaySamples(HitInfo& hitInfo, Ray& ref)
     float side = extr_glossy_sigma / (hitInfo.material.shininess * 3.0f);
     float offset = -side / 2.0f;
     std::vector<Ray> out;
-    uint32_t call = g_rng.glossCall++;
+    // the call's deviates are indexed from a hash of the reflection ray's bits (see ray_key)
+    uint32_t call = ray_key(ref.origin, ref.direction);
     for (int i = 0; i < extr_glossy_filterSize; i++) {
-        uint32_t k = (call * uint32_t(extr_glossy_filterSize) + uint32_t(i)) * 2u;
+        uint32_t k = call + 2u * uint32_t(i);
         double n0 = gauss(k), n1 = gauss(k + 1u);
         glm::vec3 rPrime = ref.direction + float(offset + n0 * side) * u + float(offset + n1 * side) * v;
         if (glm::dot(rPrime, hitInfo.normal) > 0)

@@ -754,7 +754,7 @@ __device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, R
                     g.normal = s.normal;
                     g.sum = splat3(0.0f);
                     g.next = 0;
-                    g.call = int32_t(rng.glossCall++);
+                    g.call = int32_t(rng_ray_key(ro, rd));
                     g.depth = depth;
                     state = SPAWN;
                 } else {
@@ -772,7 +772,7 @@ __device__ vec3 final_color(const FrameParams& P, vec3 origin, vec3 direction, R
             GlossyFrame& g = gframes[nGlossy - 1];
             state = RETURN;
             while (g.next < P.p.glossy_filter_size) {
-                const uint32_t k = (uint32_t(g.call) * uint32_t(P.p.glossy_filter_size) + uint32_t(g.next)) * 2u;
+                const uint32_t k = uint32_t(g.call) + 2u * uint32_t(g.next);
                 g.next++;
                 const double n0 = rng.gauss(k), n1 = rng.gauss(k + 1u);
                 const vec3 rp = (g.dir + float(double(g.offset) + n0 * double(g.side)) * g.u) + float(double(g.offset) + n1 * double(g.side)) * g.v;

@@ -59,7 +59,7 @@ RT_HD vec3 rotate(quat q, vec3 v)
 
 // Counter-based random stream: value = H(H(H(H(seed) ^ pixel) ^ (sample*0x9e3779b9 + stream)) ^ index)
 // with H a 32-bit integer finaliser.  Stream 0 replaces the reference's rand() calls in call order (31-bit
-// values), stream 1 drives the thin-lens samples, stream 2 the glossy perturbations.
+// values), stream 1 drives the thin-lens samples, stream 2 the glossy perturbations (indexed from rng_ray_key).
 RT_HD uint32_t hash32(uint32_t x)
 {
     x ^= x >> 16;
@@ -75,6 +75,25 @@ RT_HD uint32_t rng_u32(uint32_t pixelKey, uint32_t sample, uint32_t stream, uint
 {
     uint32_t h = hash32(pixelKey ^ (sample * 0x9e3779b9U + stream));
     return hash32(h ^ index);
+}
+// Key of one glossy-reflection call: a hash of the bits of the reflection ray it perturbs (origin, direction).  The
+// two Gaussian deviates of the call's sample i are deviates key + 2i and key + 2i + 1 of the glossy stream, so a call's
+// samples depend on nothing but the pixel sample and the call's own input, and calls can be evaluated in any order
+// (the reference draws them from one global generator in whatever order its threads happen to run).
+RT_HD uint32_t rng_bits(float f)
+{
+    union { float f; uint32_t u; } c;
+    c.f = f;
+    return c.u;
+}
+RT_HD uint32_t rng_ray_key(vec3 o, vec3 d)
+{
+    uint32_t h = hash32(rng_bits(o.x) ^ 0x9e3779b9U);
+    h = hash32(h ^ rng_bits(o.y));
+    h = hash32(h ^ rng_bits(o.z));
+    h = hash32(h ^ rng_bits(d.x));
+    h = hash32(h ^ rng_bits(d.y));
+    return hash32(h ^ rng_bits(d.z));
 }
 RT_HD double rng_unit(uint32_t u) { return (double(u) + 0.5) * (1.0 / 4294967296.0); }
 
