@@ -171,6 +171,9 @@ typedef struct rt_stats {
      * sample is exactly zero because the surface faces away from it) and that the library therefore does not trace;
      * shadow_rays counts traced queries only */
     uint64_t culled_shadow_rays;
+    /* calls of the reference's getFinalColor (src/render.cpp:18-80) that were evaluated as nodes of wavefront passes
+     * (one generation of the recursion per pass); 0 when the frame ran in the per-lane kernels */
+    uint64_t wavefront_nodes;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device copy of geometry, materials, textures, skybox */

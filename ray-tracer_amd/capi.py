@@ -195,6 +195,7 @@ class Stats(C.Structure):
         ("shade_ms", C.c_float),
         ("cull_ms", C.c_float),
         ("culled_shadow_rays", C.c_uint64),
+        ("wavefront_nodes", C.c_uint64),
     ]
 
     def total_rays(self):

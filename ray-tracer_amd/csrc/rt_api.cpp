@@ -90,7 +90,7 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, wfRays, wfNodes, wfMeta, wfValue, wfHitNode, wfGlossy;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
 };
 
@@ -455,7 +455,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->wfRays, &b->wfNodes, &b->wfMeta, &b->wfValue, &b->wfHitNode, &b->wfGlossy })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -650,7 +650,37 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         // hit queue of the two-kernel path: one 16-byte entry per (pixel, sample) of a pass, passes sized to
         // at most 64 Mi entries (1 GiB)
         const size_t want = nPix * size_t(spp);
-        const size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
+        size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
+        // Wavefront evaluation of bounce features: node buffers for the call trees of a chunk of pixel samples, and a
+        // hit queue with an entry per node.  By default only frames with glossy reflection take it (their fan-out is what
+        // a lane of the general kernel cannot keep up with); RT_WAVEFRONT=1 sends every frame with a bounce feature
+        // through it, RT_WAVEFRONT=0 none.
+        static const int wavefrontMode = [] {
+            const char* e = std::getenv("RT_WAVEFRONT");
+            return e ? std::atoi(e) : -1;
+        }();
+        const bool bounce = features->recursive || features->glossy || features->transparency || (features->environment_mapping && params->enabled_refl_map);
+        if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && features->glossy))) {
+            size_t nodes = 4 * want;
+            if (nodes < (size_t(1) << 20)) nodes = size_t(1) << 20;
+            if (nodes > (size_t(24) << 20)) nodes = size_t(24) << 20;
+            const size_t calls = nodes / size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1) + 64;
+            RT_HIP(b->wfRays.reserve(nodes * sizeof(WfRay)));
+            RT_HIP(b->wfNodes.reserve(nodes * sizeof(WfNode)));
+            RT_HIP(b->wfMeta.reserve(nodes * sizeof(uint32_t)));
+            RT_HIP(b->wfValue.reserve(nodes * 12));
+            RT_HIP(b->wfHitNode.reserve(2 * nodes * sizeof(uint32_t))); // one per hit-queue entry
+            RT_HIP(b->wfGlossy.reserve(calls * sizeof(WfGlossy)));
+            P.wfRays = static_cast<WfRay*>(b->wfRays.ptr);
+            P.wfNodes = static_cast<WfNode*>(b->wfNodes.ptr);
+            P.wfMeta = static_cast<uint32_t*>(b->wfMeta.ptr);
+            P.wfValue = static_cast<float*>(b->wfValue.ptr);
+            P.wfHitNode = static_cast<uint32_t*>(b->wfHitNode.ptr);
+            P.wfGlossy = static_cast<WfGlossy*>(b->wfGlossy.ptr);
+            P.wfCapacity = uint32_t(nodes);
+            P.wfGlossyCapacity = uint32_t(calls);
+            if (cap < 2 * nodes) cap = 2 * nodes; // a chunk has at most `nodes` roots and `nodes` nodes, each with at most one hit entry
+        }
         RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
         RT_HIP(b->queueCounters.reserve(Q_COUNT * sizeof(unsigned long long)));
         const size_t items = cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1);
@@ -681,7 +711,8 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     const bool wait = stats != nullptr || !devicePtr;
     if (stats) RT_HIP(hipEventRecord(b->evStart, s));
     bool splitRecorded = false;
-    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr, stats ? b->evSplit : nullptr, &splitRecorded));
+    unsigned long long wavefrontNodes = 0;
+    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr, stats ? b->evSplit : nullptr, &splitRecorded, &wavefrontNodes));
     if (stats) RT_HIP(hipEventRecord(b->evStop, s));
     if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
     if (wait) RT_HIP(hipStreamSynchronize(s));
@@ -700,6 +731,7 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         stats->shadow_box_tests = h[STAT_SHADOW_BOX];
         stats->shadow_triangle_tests = h[STAT_SHADOW_TRI];
         stats->culled_shadow_rays = h[STAT_CULLED];
+        stats->wavefront_nodes = wavefrontNodes;
         if (splitRecorded) {
             RT_HIP(hipEventElapsedTime(&stats->primary_ms, b->evStart, b->evSplit[0]));
             RT_HIP(hipEventElapsedTime(&stats->cull_ms, b->evSplit[0], b->evSplit[1]));

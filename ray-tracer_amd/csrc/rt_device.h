@@ -28,6 +28,47 @@ struct LightDev {
 
 enum { MAX_LIGHTS = 16 };
 
+// Wavefront evaluation of the reference's recursion (src/render.cpp:18-80): the call tree of every pixel sample of a
+// chunk is laid out as nodes, generation by generation (a generation = the calls at one recursion depth), each
+// generation a contiguous range.  A node is one getFinalColor call: its ray, what the call found, and what it still
+// waits for.
+enum {
+    WF_DEAD = 0,    // no call (a glossy sample below the surface, a lens ray of a pixel in focus): contributes nothing
+    WF_PENDING = 1, // ray written, not traced yet
+    WF_MISS = 2,    // value = sky box texel or black
+    WF_VALUE = 3,   // value set at the hit (reflection map)
+    WF_LO = 4,      // value = direct lighting Lo (written to coef by the shade pass)
+    WF_BLEND = 5,   // value = a * Lo + (1 - a) * child          (render.cpp:43)
+    WF_MIRROR = 6,  // value = ks * child                        (render.cpp:61)
+    WF_GLOSSY = 7   // value = ks * (sum of children) / filter   (render.cpp:53-59)
+};
+struct WfRay {
+    float o[3], d[3];
+    uint32_t work;   // (sample - sampleBegin) * pixels + pixel of the pixel sample the call belongs to
+    uint32_t parent; // node index of the calling node (unused for roots)
+};
+// (a node's meta word — kind | specular depth left << 4 | see-through nesting << 8 | WF_ROOT — and its value live in
+// arrays of their own: the passes that only skip or sum nodes touch 4 or 12 bytes per node instead of the record)
+struct WfNode {
+    float t;
+    int32_t slot;
+    uint32_t firstChild;
+    uint32_t randBase; // index on the rand() stream of the first draw this call's lighting consumes
+    float coef[3];     // WF_MIRROR / WF_GLOSSY: ks; WF_BLEND: Lo (written by the shade pass)
+    float a;           // WF_BLEND: the material's transparency
+};
+// what a glossy call hands to the lanes that generate its samples (src/gloss.cpp:14-51)
+struct WfGlossy {
+    float origin[3], dir[3], normal[3];
+    float side;
+    uint32_t node, key;
+};
+enum : uint32_t { WF_ROOT = 1u << 16 }; // the node of a pixel sample's own call
+__host__ __device__ inline uint32_t wf_kind(uint32_t meta) { return meta & 15u; }
+__host__ __device__ inline uint32_t wf_depth(uint32_t meta) { return (meta >> 4) & 15u; }
+__host__ __device__ inline uint32_t wf_blend_depth(uint32_t meta) { return (meta >> 8) & 255u; }
+__host__ __device__ inline uint32_t wf_meta(uint32_t kind, uint32_t depth, uint32_t blendDepth) { return kind | (depth << 4) | (blendDepth << 8); }
+
 struct FrameParams {
     SceneView scene;
     quat camQ;
@@ -68,6 +109,19 @@ struct FrameParams {
     uint32_t pairSpillEntries;
     uint32_t pairSpillWaves;
     int32_t streamGroup;         // shadow pass: consecutive queries that share a stack entry (1, 2 or 4)
+    // wavefront evaluation of bounce features (null / zero when the call does not use it)
+    WfRay* wfRays;
+    WfNode* wfNodes;
+    uint32_t* wfMeta;
+    float* wfValue;        // [node][rgb]
+    uint32_t* wfHitNode;   // hit-queue entry -> node whose direct lighting it is
+    WfGlossy* wfGlossy;    // glossy calls of the current generation
+    uint32_t wfCapacity;   // nodes
+    uint32_t wfGlossyCapacity;
+    uint32_t wfBegin, wfEnd; // node range of the generation a kernel works on
+    uint32_t wfRootBegin;    // work id of the chunk's first root
+    int32_t wfLighting;      // the queue passes read their rays from the nodes and write Lo there
+    int32_t wfRootsTurn;     // k_wf_combine: evaluate the pixel samples' own nodes (else: every other node)
 };
 
 // Device counters of a pass.  Each sits in a 128-byte line of its own: atomics on one line are served one after the
@@ -79,7 +133,10 @@ enum {
     Q_GAVE_UP_PACKETS = 48,  // packets of given-up camera rays handed out
     Q_GAVE_UP = 64,          // camera rays that gave up
     Q_PRIMARY_CURSORS = 80,  // 16 cursors (one per 128-byte line) that hand out k_primary's chunks of logical blocks
-    Q_COUNT = 80 + 16 * 16
+    Q_WF_NODES = 80 + 16 * 16,     // wavefront: nodes allocated so far in the chunk
+    Q_WF_GLOSSY = Q_WF_NODES + 16, // glossy calls of the current generation
+    Q_WF_OVERFLOW = Q_WF_GLOSSY + 16, // set when a generation did not fit the node or glossy capacity
+    Q_COUNT = Q_WF_OVERFLOW + 16
 };
 
 struct Counts {

@@ -12,7 +12,10 @@ enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TR
 // the resolve pass.  `afterPasses`, when not null, is recorded between the two.  `split`, when not null, points
 // to four events recorded after the primary, cull, shadow and shade kernels if the call runs as those three passes
 // in a single chunk; *splitRecorded says whether that happened.
-hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded);
+// *wavefrontNodes (when not null) receives the number of call-tree nodes the wavefront passes evaluated (0 when the
+// call did not run as wavefront passes).
+hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded,
+    unsigned long long* wavefrontNodes = nullptr);
 
 // Shadow pass sizing: clamps P.pairStackLds to what the hierarchy can need and sets P.pairSpillEntries (per wave)
 // and P.pairSpillWaves (the most waves the pass is launched with); the caller provides P.pairSpill accordingly.

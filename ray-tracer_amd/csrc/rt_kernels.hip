@@ -2,6 +2,8 @@
 // ray/triangle decisions must round exactly like the reference's scalar fp32 code.
 #include "rt_kernels.h"
 
+#include <vector>
+
 namespace rt {
 
 namespace {
@@ -89,16 +91,38 @@ __global__ void __launch_bounds__(WAVE) k_render(const FrameParams P)
     flush_counts(cnt, P.stats);
 }
 
-// Recomputes the camera ray of a queued hit from its work id.
-__device__ __forceinline__ void hit_ray(const FrameParams& P, const HitEntry& e, uint32_t nPix, Rng& rng, RayD& r, size_t& pix, int& sidx)
+// The ray whose hit is entry q of the hit queue, and the state of its random streams.  Direct-lighting frames: the
+// camera ray, recomputed from the entry's work id.  Wavefront lighting: the ray of the node the entry belongs to; the
+// node also knows where on the rand() stream its call's lighting starts.
+__device__ __forceinline__ void hit_ray(const FrameParams& P, uint32_t q, const HitEntry& e, uint32_t nPix, Rng& rng, RayD& r, size_t& pix, int& sidx)
 {
     sidx = P.sampleBegin + int(e.work / nPix);
     pix = size_t(e.work % nPix);
     const int x = int(pix % size_t(P.width));
     const int y = local_row_y(P, int(pix / size_t(P.width)));
+    if (P.wfLighting && P.wfHitNode[q] != 0xffffffffu) {
+        const uint32_t node = P.wfHitNode[q];
+        const WfRay& w = P.wfRays[node];
+        rng.pixelKey = rng_pixel_key(P.p.seed, uint32_t(y * P.width + x));
+        rng.glossCall = 0;
+        rng.sample = uint32_t(sidx);
+        rng.randCounter = P.wfNodes[node].randBase;
+        r = make_ray(load3(w.o), load3(w.d));
+        return;
+    }
     vec3 o, d;
     sample_camera_ray(P, x, y, sidx, rng, o, d);
     r = make_ray(o, d);
+}
+// where the colour of queued hit q goes: the pixel sample's slot, or the Lo of its node
+__device__ __forceinline__ float* hit_colour_slot(const FrameParams& P, uint32_t q, size_t pix, int sidx)
+{
+    if (P.wfLighting && P.wfHitNode[q] != 0xffffffffu) {
+        // a see-through call keeps its Lo for the blend; a call that ends here has Lo as its value
+        const uint32_t node = P.wfHitNode[q];
+        return wf_kind(P.wfMeta[node]) == WF_BLEND ? P.wfNodes[node].coef : P.wfValue + 3 * size_t(node);
+    }
+    return sample_slot(P, pix, sidx);
 }
 
 // Primary pass.  Three kernels:
@@ -223,7 +247,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
         RayD r;
         size_t pix;
         int sidx;
-        hit_ray(P, e, nPix, rng, r, pix, sidx);
+        hit_ray(P, q, e, nPix, rng, r, pix, sidx);
         float t = FLT_MAX;
         e.slot = intersect<PRUNE, false, COUNT>(P, r, t, st, cnt);
         e.t = t;
@@ -273,7 +297,7 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
             if (live) {
                 size_t pix;
                 int sidx;
-                hit_ray(P, e, nPix, rng, r, pix, sidx);
+                hit_ray(P, q, e, nPix, rng, r, pix, sidx);
                 s = surface_at(P, r, e.t, e.slot);
                 t = e.t;
             }
@@ -311,7 +335,7 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                             wanted = (wantedBits >> j) & 1ull;
                         } else if (P.f.shading) {
                             vec3 position, color;
-                            light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
+                            light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
                             wanted = dot(N, normalize(position - point)) > 0; // same expression as phong()
                         }
                         const uint32_t item = q * perHit + uint32_t(j);
@@ -330,7 +354,7 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
         // zeros (+0 + -0 = +0): its colour is written here and k_shade skips it.
         if (live && need == 0 && P.f.shading && everyLightShadowed) {
             const HitEntry e = P.queue[q];
-            float* out = sample_slot(P, size_t(e.work % nPix), P.sampleBegin + int(e.work / nPix));
+            float* out = hit_colour_slot(P, q, size_t(e.work % nPix), P.sampleBegin + int(e.work / nPix));
             out[0] = 0.0f;
             out[1] = 0.0f;
             out[2] = 0.0f;
@@ -540,7 +564,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 Rng rng;
                 size_t pix;
                 int sidx;
-                hit_ray(P, e, nPix, rng, r, pix, sidx);
+                hit_ray(P, 0u, e, nPix, rng, r, pix, sidx); // (a camera ray: never a wavefront node)
             } else {
                 work = P.shadowQueue[qi];
                 const HitEntry e = P.queue[work / perHit];
@@ -549,7 +573,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 RayD cam;
                 size_t pix;
                 int sidx;
-                hit_ray(P, e, nPix, rng, cam, pix, sidx);
+                hit_ray(P, work / perHit, e, nPix, rng, cam, pix, sidx);
                 // which light and which of its samples: the last light whose first shadow sample is <= j
                 int li = 0;
                 for (int i = 0; i < P.nLights; i++)
@@ -557,7 +581,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 const LightDev& L = P.lights[li];
                 const int k = j - L.shadowBase;
                 vec3 position, color;
-                light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
                 const float epsilon = 0.00001f;
                 const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
                 r = make_ray(origin, position - origin);
@@ -777,7 +801,7 @@ __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
         RayD r;
         size_t pix;
         int sidx;
-        hit_ray(P, e, nPix, rng, r, pix, sidx);
+        hit_ray(P, q, e, nPix, rng, r, pix, sidx);
         const Surface s = surface_at(P, r, e.t, e.slot);
         const uint8_t* vis = P.visibility + size_t(q) * size_t(P.shadowSamplesPerHit);
         vec3 shading = splat3(0.0f);
@@ -789,13 +813,13 @@ __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
             const uint32_t per = light_draws_per_sample(L.type);
             for (int k = 0; k < total; k++) {
                 vec3 position, color;
-                light_sample(L, k, rng.pixelKey, rng.sample, 2u + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
+                light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
                 const float lighted = shadowed ? float(vis[L.shadowBase + k]) : 1.0f;
                 const vec3 shade = P.f.shading ? phong(position, color, r, e.t, s) : s.kd;
                 shading = shading + light_weight(L, shade) * lighted;
             }
         }
-        float* out = sample_slot(P, pix, sidx);
+        float* out = hit_colour_slot(P, q, pix, sidx);
         out[0] = shading.x;
         out[1] = shading.y;
         out[2] = shading.z;
@@ -913,6 +937,327 @@ __global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, 
     dst[idx * 3 + 2] = o.z;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Wavefront evaluation of frames with bounce features (mirror reflection, see-through continuation, glossy
+// reflection, reflection map): the reference's recursion (src/render.cpp:18-80) laid out as a tree of nodes per pixel
+// sample and evaluated one generation at a time, so that every ray of a generation — however many calls a pixel
+// sample has spawned — gets a lane of its own:
+//   k_wf_trace    closest hit of every pending ray of a generation (the first launch of a chunk: of its camera rays,
+//                 generated on the fly), then the branch of getFinalColor the call takes:
+//                 what kind of node it becomes, the nodes of its children (allocated with one atomic per wave, so the
+//                 children of a wave's hits are adjacent), and, where its value needs the direct lighting Lo, an
+//                 entry in the hit queue;
+//   k_wf_spawn    the sample rays of the generation's glossy calls, one lane per (call, sample);
+//   (the queue passes k_cull / k_stream / k_shade: Lo of every queued hit, all generations at once)
+//   k_wf_combine  values bottom-up, one generation per launch, with the reference's operations in its order; the
+//                 roots write the pixel samples.
+// A call's random draws do not depend on the evaluation order: light jitter is indexed from the node's randBase
+// (chains of single children advance it like the recursion does), glossy deviates from a hash of the reflection ray.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wf_pixel(const FrameParams& P, uint32_t work, uint32_t nPix, size_t& pix, int& sidx, int& x, int& y)
+{
+    sidx = P.sampleBegin + int(work / nPix);
+    pix = size_t(work % nPix);
+    x = int(pix % size_t(P.width));
+    y = local_row_y(P, int(pix / size_t(P.width)));
+}
+
+// ROOTS = true: the lanes are the pixel samples of the chunk themselves (work ids wfBegin .. wfEnd - 1 counted from
+// wfRootBegin); their camera rays are generated here and only the samples whose call spawns another call get a node
+// (most end at their first hit or miss: those write their pixel sample, or queue their hit for the lighting passes,
+// directly).  ROOTS = false: the lanes are the nodes wfBegin .. wfEnd - 1 of a generation.
+template <bool PRUNE, bool COUNT, bool ROOTS>
+__global__ void __launch_bounds__(WAVE) k_wf_trace(const FrameParams P)
+{
+    extern __shared__ uint2 lds_stack[];
+    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    Counts cnt;
+    const int lane = int(threadIdx.x);
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
+    const uint32_t n = P.wfEnd - P.wfBegin;
+    const uint32_t rounded = (n + 63u) & ~63u; // whole waves stay in the loop together
+    const bool reflMap = P.f.environment_mapping && P.p.enabled_refl_map;
+    const uint32_t filter = uint32_t(P.p.glossy_filter_size);
+    for (uint32_t i = blockIdx.x * WAVE + threadIdx.x; i < rounded; i += gridDim.x * WAVE) {
+        uint32_t node = P.wfBegin + i; // ROOTS: assigned below, and only if the sample's call has children
+        uint32_t kind = WF_DEAD, nChildren = 0, depth = 0, blendDepth = 0, randBase = 0;
+        bool pending = false, wantsLo = false;
+        RayD r = make_ray(splat3(0.0f), splat3(1.0f));
+        float t = FLT_MAX;
+        int slot = -1;
+        Surface s;
+        uint32_t work = 0;
+        size_t pix = 0;
+        int sidx = 0;
+        if (i < n) {
+            if (ROOTS) {
+                work = P.wfRootBegin + P.wfBegin + i;
+                int x, y;
+                wf_pixel(P, work, nPix, pix, sidx, x, y);
+                // depth of field: the lens rays of a pixel exist only when its centre ray (an earlier pass) said so
+                pending = !(P.f.depth_of_field && sidx > 0 && P.dofFlags[pix] == 0);
+                if (pending) {
+                    Rng rng;
+                    vec3 o, d;
+                    sample_camera_ray(P, x, y, sidx, rng, o, d);
+                    r = make_ray(o, d);
+                    randBase = rng.randCounter;
+                    depth = uint32_t(P.p.ray_depth);
+                    cnt.primary++;
+                }
+            } else {
+                const uint32_t meta = P.wfMeta[node];
+                pending = wf_kind(meta) == WF_PENDING;
+                if (pending) {
+                    const WfRay w = P.wfRays[node];
+                    work = w.work;
+                    r = make_ray(load3(w.o), load3(w.d));
+                    depth = wf_depth(meta);
+                    blendDepth = wf_blend_depth(meta);
+                    randBase = P.wfNodes[node].randBase;
+                    cnt.bounce++;
+                }
+            }
+            if (pending) {
+                Attr attr;
+                slot = traverse<PRUNE, false, COUNT, false>(P.scene, r, t, st, cnt, attr);
+                if (ROOTS && P.f.depth_of_field && sidx == 0) P.dofFlags[pix] = dof_flag(P, r.d, slot >= 0 ? t : FLT_MAX) ? 1 : 0;
+                if (slot < 0) {
+                    kind = WF_MISS;
+                } else {
+                    // the branch of getFinalColor this call takes (render.cpp:25-67)
+                    s = surface_at(P, r, t, slot);
+                    const bool blend = !reflMap && P.f.transparency && s.transparency != 1.0f;
+                    const bool specular = !reflMap && !blend && (P.f.recursive || P.f.glossy) && depth > 0 && (s.ks.x != 0 || s.ks.y != 0 || s.ks.z != 0);
+                    if (reflMap) {
+                        kind = WF_VALUE;
+                    } else if (blend) {
+                        if (int(blendDepth) >= P.p.max_transparency_depth) {
+                            cnt.overflow++;
+                            kind = WF_LO;
+                        } else {
+                            kind = WF_BLEND;
+                            nChildren = 1;
+                        }
+                        wantsLo = true;
+                    } else if (specular) {
+                        kind = P.f.glossy ? WF_GLOSSY : WF_MIRROR;
+                        nChildren = kind == WF_GLOSSY ? filter : 1u;
+                    } else {
+                        kind = WF_LO;
+                        wantsLo = true;
+                    }
+                }
+            }
+        }
+        // a glossy call without samples is ks * 0 / 0 in the reference (render.cpp:59) and here: it keeps a node
+        const bool hasNode = !ROOTS || nChildren > 0 || kind == WF_GLOSSY;
+        const uint32_t need = nChildren + ((ROOTS && hasNode && pending) ? 1u : 0u);
+        // ---- nodes for the children (and for a root that has any): one atomic per wave
+        uint32_t prefix = need; // inclusive scan over the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(prefix, off, 64);
+            if (lane >= off) prefix += v;
+        }
+        const uint32_t total = __shfl(prefix, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 63 && total) base = atomicAdd(&P.queueCounters[Q_WF_NODES], (unsigned long long)total);
+        base = __shfl(base, 63, 64);
+        uint32_t firstChild = uint32_t(base) + prefix - need;
+        if (ROOTS && need) node = firstChild++;
+        bool fitsNodes = base + total <= (unsigned long long)P.wfCapacity;
+        if (total && !fitsNodes && lane == 63) P.queueCounters[Q_WF_OVERFLOW] = 1ull;
+        // ---- glossy calls of this generation: one list entry each
+        const unsigned long long glossyVotes = __ballot(kind == WF_GLOSSY && nChildren > 0);
+        uint32_t glossyAt = 0;
+        if (glossyVotes) {
+            const int leader = __ffsll((long long)glossyVotes) - 1;
+            unsigned long long gb = 0;
+            if (lane == leader) gb = atomicAdd(&P.queueCounters[Q_WF_GLOSSY], (unsigned long long)__popcll(glossyVotes));
+            gb = __shfl(gb, leader, 64);
+            if (gb + (unsigned long long)__popcll(glossyVotes) > (unsigned long long)P.wfGlossyCapacity) {
+                fitsNodes = false;
+                if (lane == leader) P.queueCounters[Q_WF_OVERFLOW] = 1ull;
+            }
+            glossyAt = uint32_t(gb) + lanes_below(glossyVotes);
+        }
+        // ---- hit queue entries of the calls whose value needs Lo (the queue holds an entry per root and per node)
+        const unsigned long long loVotes = __ballot(wantsLo);
+        uint32_t hitAt = 0;
+        if (loVotes) {
+            const int leader = __ffsll((long long)loVotes) - 1;
+            unsigned long long hb = 0;
+            if (lane == leader) hb = atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(loVotes));
+            hb = __shfl(hb, leader, 64);
+            hitAt = uint32_t(hb) + lanes_below(loVotes);
+        }
+        if (!pending) continue;
+        if (!fitsNodes && need) {
+            // the chunk is abandoned and rendered again in smaller pieces; leave nothing half-written behind
+            kind = WF_MISS;
+            nChildren = 0;
+            wantsLo = false;
+        }
+        const bool nodeWritten = !ROOTS || (hasNode && fitsNodes);
+        if (wantsLo) {
+            HitEntry e;
+            e.work = work;
+            e.t = t;
+            e.slot = slot;
+            e.pad = 0;
+            P.queue[hitAt] = e;
+            P.wfHitNode[hitAt] = nodeWritten ? node : 0xffffffffu; // no node: a camera ray's hit, coloured into its pixel sample
+        }
+        if (kind == WF_MISS || kind == WF_VALUE) {
+            const vec3 c = (kind == WF_VALUE || (P.f.environment_mapping && P.p.enabled_skybox)) ? skybox_color(P.scene, r.d) : splat3(0.0f);
+            float* v = nodeWritten ? P.wfValue + 3 * size_t(node) : sample_slot(P, pix, sidx);
+            v[0] = c.x; v[1] = c.y; v[2] = c.z;
+        }
+        if (!nodeWritten) continue;
+        WfNode& nd = P.wfNodes[node];
+        nd.t = t;
+        nd.slot = slot;
+        nd.firstChild = firstChild;
+        P.wfMeta[node] = wf_meta(kind, depth, blendDepth) | (ROOTS ? WF_ROOT : 0u);
+        if (ROOTS) {
+            nd.randBase = randBase;
+            WfRay& w = P.wfRays[node];
+            w.o[0] = r.o.x; w.o[1] = r.o.y; w.o[2] = r.o.z;
+            w.d[0] = r.d.x; w.d[1] = r.d.y; w.d[2] = r.d.z;
+            w.work = work;
+            w.parent = 0xffffffffu;
+        }
+        const uint32_t childRand = randBase + uint32_t(P.drawsPerHit); // the call's lighting draws come before its child's
+        if (kind == WF_BLEND) {
+            nd.a = s.transparency;
+            const vec3 o = (t + 0.000001f) * r.d + r.o; // render.cpp:40
+            WfRay& w = P.wfRays[firstChild];
+            w.o[0] = o.x; w.o[1] = o.y; w.o[2] = o.z;
+            w.d[0] = r.d.x; w.d[1] = r.d.y; w.d[2] = r.d.z;
+            w.work = work;
+            w.parent = node;
+            P.wfMeta[firstChild] = wf_meta(WF_PENDING, depth, blendDepth + 1u);
+            P.wfNodes[firstChild].randBase = childRand;
+        } else if (kind == WF_MIRROR || kind == WF_GLOSSY) {
+            nd.coef[0] = s.ks.x; nd.coef[1] = s.ks.y; nd.coef[2] = s.ks.z;
+            // computeReflectionRay, reference src/shading.cpp:42-51
+            const float epsilon = 0.00001f;
+            const vec3 rd = r.d - (2 * dot(r.d, s.normal)) * s.normal;
+            const vec3 ro = t * r.d * (1 - epsilon) + r.o;
+            if (kind == WF_MIRROR) {
+                WfRay& w = P.wfRays[firstChild];
+                w.o[0] = ro.x; w.o[1] = ro.y; w.o[2] = ro.z;
+                w.d[0] = rd.x; w.d[1] = rd.y; w.d[2] = rd.z;
+                w.work = work;
+                w.parent = node;
+                P.wfMeta[firstChild] = wf_meta(WF_PENDING, depth - 1u, blendDepth);
+                P.wfNodes[firstChild].randBase = childRand;
+            } else if (nChildren) {
+                WfGlossy& g = P.wfGlossy[glossyAt];
+                g.origin[0] = ro.x; g.origin[1] = ro.y; g.origin[2] = ro.z;
+                g.dir[0] = rd.x; g.dir[1] = rd.y; g.dir[2] = rd.z;
+                g.normal[0] = s.normal.x; g.normal[1] = s.normal.y; g.normal[2] = s.normal.z;
+                g.side = P.p.glossy_sigma / (s.shininess * 3.0f);
+                g.node = node;
+                g.key = rng_ray_key(ro, rd);
+            }
+        }
+    }
+    flush_counts(cnt, P.stats);
+}
+
+// One lane per (glossy call of the generation, sample): the perturbed reflection ray of reference src/gloss.cpp:14-51,
+// same arithmetic as the glossy frames of final_color.
+__global__ void __launch_bounds__(BLOCK) k_wf_spawn(const FrameParams P)
+{
+    const uint32_t filter = uint32_t(P.p.glossy_filter_size);
+    const unsigned long long calls = P.queueCounters[Q_WF_GLOSSY];
+    const unsigned long long n = calls * filter;
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
+    for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) {
+        const WfGlossy g = P.wfGlossy[i / filter];
+        const uint32_t k = uint32_t(i % filter);
+        const WfNode& parent = P.wfNodes[g.node];
+        const uint32_t parentMeta = P.wfMeta[g.node];
+        const uint32_t child = parent.firstChild + k;
+        const uint32_t work = P.wfRays[g.node].work;
+        size_t pix;
+        int sidx, x, y;
+        wf_pixel(P, work, nPix, pix, sidx, x, y);
+        Rng rng;
+        rng.pixelKey = rng_pixel_key(P.p.seed, uint32_t(y * P.width + x));
+        rng.sample = uint32_t(sidx);
+        const vec3 dir = load3(g.dir), normal = load3(g.normal);
+        const vec3 w = normalize(dir);
+        const float awx = fabsf(w.x), awy = fabsf(w.y), awz = fabsf(w.z);
+        const int minTerm = (awx <= awy && awx <= awz) ? 0 : ((awy <= awx && awy <= awz) ? 1 : 2);
+        vec3 tt = w;
+        if (minTerm == 0) tt.x = 1; else if (minTerm == 1) tt.y = 1; else tt.z = 1;
+        const vec3 u = normalize(cross(tt, w));
+        const vec3 v = cross(w, u);
+        const float offset = -g.side / 2.0f;
+        const uint32_t idx = g.key + 2u * k;
+        const double n0 = rng.gauss(idx), n1 = rng.gauss(idx + 1u);
+        const vec3 rp = (dir + float(double(offset) + n0 * double(g.side)) * u) + float(double(offset) + n1 * double(g.side)) * v;
+        WfNode& nd = P.wfNodes[child];
+        if (dot(rp, normal) > 0) {
+            const vec3 d = normalize(rp);
+            WfRay& ray = P.wfRays[child];
+            ray.o[0] = g.origin[0]; ray.o[1] = g.origin[1]; ray.o[2] = g.origin[2];
+            ray.d[0] = d.x; ray.d[1] = d.y; ray.d[2] = d.z;
+            ray.work = work;
+            ray.parent = g.node;
+            P.wfMeta[child] = wf_meta(WF_PENDING, wf_depth(parentMeta) - 1u, wf_blend_depth(parentMeta));
+            nd.randBase = parent.randBase + uint32_t(P.drawsPerHit);
+        } else {
+            P.wfMeta[child] = wf_meta(WF_DEAD, 0, 0);
+        }
+    }
+}
+
+// Values of one generation from those of the next (launched from the deepest generation upwards).  The nodes of the
+// pixel samples themselves sit in the first generation's range next to their children: they are skipped there and
+// evaluated by a last launch of their own (wfRootsTurn), which also writes the pixel samples.
+__global__ void __launch_bounds__(BLOCK) k_wf_combine(const FrameParams P)
+{
+    const uint32_t n = P.wfEnd - P.wfBegin;
+    const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
+    const int filter = P.p.glossy_filter_size;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t node = P.wfBegin + i;
+        const uint32_t meta = P.wfMeta[node];
+        const uint32_t kind = wf_kind(meta);
+        const bool root = (meta & WF_ROOT) != 0u;
+        // (the value of a call that ends at its hit or miss was written where it was found: nothing to combine)
+        if ((kind != WF_BLEND && kind != WF_MIRROR && kind != WF_GLOSSY) || root != (P.wfRootsTurn != 0)) continue;
+        const WfNode& nd = P.wfNodes[node];
+        vec3 result;
+        if (kind == WF_BLEND) {
+            const vec3 child = load3(P.wfValue + 3 * size_t(nd.firstChild));
+            result = nd.a * load3(nd.coef) + (1.0f - nd.a) * child; // render.cpp:43
+        } else if (kind == WF_MIRROR) {
+            result = load3(nd.coef) * load3(P.wfValue + 3 * size_t(nd.firstChild)); // render.cpp:61
+        } else {
+            vec3 sum = splat3(0.0f);
+            for (int k = 0; k < filter; k++) {
+                const uint32_t c = nd.firstChild + uint32_t(k);
+                if (wf_kind(P.wfMeta[c]) != WF_DEAD) sum = sum + load3(P.wfValue + 3 * size_t(c));
+            }
+            result = load3(nd.coef) * sum / float(filter); // render.cpp:59
+        }
+        if (root) {
+            size_t pix;
+            int sidx, x, y;
+            wf_pixel(P, P.wfRays[P.wfBegin + i].work, nPix, pix, sidx, x, y);
+            float* out = sample_slot(P, pix, sidx);
+            out[0] = result.x; out[1] = result.y; out[2] = result.z;
+        } else {
+            float* v = P.wfValue + 3 * size_t(node);
+            v[0] = result.x; v[1] = result.y; v[2] = result.z;
+        }
+    }
+}
+
 size_t stack_bytes(const FrameParams& P, int threads)
 {
     int depth = P.scene.stackDepth < 1 ? 1 : P.scene.stackDepth;
@@ -1022,6 +1367,104 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
     return hipGetLastError();
 }
 
+
+// Renders the pixel samples [sBegin, sEnd) of the call's rows as wavefront passes, in chunks of roots sized so that
+// the call trees of a chunk fit the node buffer.  A chunk that turns out not to fit (the fan-out of glossy calls is
+// only known once they are traced) is abandoned and rendered again as smaller chunks; what a node computes does not
+// depend on the chunking.  The generation loop needs the node count of each generation on the host, so this path
+// waits on the stream once per generation.
+template <bool PRUNE>
+hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipStream_t stream, unsigned long long& nodesEvaluated)
+{
+    hipError_t e;
+    P.sampleBegin = sBegin;
+    P.sampleEnd = sEnd;
+    const unsigned long long totalRoots = (unsigned long long)P.rowsLocal * (unsigned long long)P.width * (unsigned long long)(sEnd - sBegin);
+    unsigned long long chunk = P.wfCapacity; // (the hit queue holds an entry per root and per node)
+    if (chunk < 1) chunk = 1;
+    unsigned long long done = 0;
+    unsigned long long host[Q_COUNT - Q_WF_NODES];
+    unsigned long long statsBackup[STAT_COUNT];
+    std::vector<uint32_t> gens;
+    while (done < totalRoots) {
+        const uint32_t nRoots = uint32_t(totalRoots - done < chunk ? totalRoots - done : chunk);
+        if ((e = hipMemsetAsync(P.queueCounters, 0, Q_COUNT * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+        // the ray counters of an abandoned chunk must not stay in the statistics
+        if (P.stats && (e = hipMemcpyAsync(statsBackup, P.stats, sizeof statsBackup, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; // (the two host buffers above are reused)
+        P.wfRootBegin = uint32_t(done);
+        P.wfBegin = 0;
+        P.wfEnd = nRoots;
+        P.wfLighting = 0;
+        P.wfRootsTurn = 0;
+        gens.clear();
+        gens.push_back(0);
+        bool overflow = false;
+        bool roots = true;
+        while (true) {
+            const uint32_t n = P.wfEnd - P.wfBegin;
+            const uint32_t waves = (n + WAVE - 1) / WAVE;
+            uint32_t cap;
+            if (roots) cap = P.countTests ? resident_blocks(k_wf_trace<PRUNE, true, true>, WAVE, lds) : resident_blocks(k_wf_trace<PRUNE, false, true>, WAVE, lds);
+            else cap = P.countTests ? resident_blocks(k_wf_trace<PRUNE, true, false>, WAVE, lds) : resident_blocks(k_wf_trace<PRUNE, false, false>, WAVE, lds);
+            const dim3 grid(waves < cap ? waves : cap);
+            if (roots) {
+                if (P.countTests) hipLaunchKernelGGL((k_wf_trace<PRUNE, true, true>), grid, dim3(WAVE), lds, stream, P);
+                else hipLaunchKernelGGL((k_wf_trace<PRUNE, false, true>), grid, dim3(WAVE), lds, stream, P);
+            } else {
+                if (P.countTests) hipLaunchKernelGGL((k_wf_trace<PRUNE, true, false>), grid, dim3(WAVE), lds, stream, P);
+                else hipLaunchKernelGGL((k_wf_trace<PRUNE, false, false>), grid, dim3(WAVE), lds, stream, P);
+            }
+            if (P.f.glossy) hipLaunchKernelGGL(k_wf_spawn, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+            if ((e = hipMemcpyAsync(host, &P.queueCounters[Q_WF_NODES], sizeof host, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            if (host[Q_WF_OVERFLOW - Q_WF_NODES] != 0) {
+                overflow = true;
+                break;
+            }
+            const uint32_t nodes = uint32_t(host[0]);
+            if (nodes == gens.back()) break; // no call of this generation made another
+            if ((e = hipMemsetAsync(&P.queueCounters[Q_WF_GLOSSY], 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            P.wfBegin = gens.back();
+            P.wfEnd = nodes;
+            gens.push_back(nodes);
+            roots = false;
+        }
+        if (overflow) {
+            if (nRoots <= 1) return hipErrorOutOfMemory; // one pixel sample's call tree exceeds the node buffer
+            if (P.stats && (e = hipMemcpyAsync(P.stats, statsBackup, sizeof statsBackup, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            chunk = nRoots / 2u;
+            continue;
+        }
+        // direct lighting of every call that needs it, all generations at once
+        P.wfLighting = 1;
+        if (P.shadowSamplesPerHit > 0) {
+            hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+            launch_stream<false>(P, 256u * 32u, stream_lds_bytes(P.pairStackLds), stream);
+        }
+        hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+        P.wfLighting = 0;
+        // values, deepest generation first; the pixel samples' own nodes (in the first range) last
+        for (int turn = 0; turn < 2; turn++) {
+            P.wfRootsTurn = turn;
+            for (size_t g = gens.size() - 1; g-- > 0;) {
+                if (turn == 1 && g != 0) continue;
+                P.wfBegin = gens[g];
+                P.wfEnd = gens[g + 1];
+                const uint32_t n = P.wfEnd - P.wfBegin;
+                const uint32_t blocks = (n + BLOCK - 1) / BLOCK;
+                hipLaunchKernelGGL(k_wf_combine, dim3(blocks < 256u * 16u ? blocks : 256u * 16u), dim3(BLOCK), 0, stream, P);
+            }
+        }
+        P.wfRootsTurn = 0;
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        nodesEvaluated += (unsigned long long)nRoots + gens.back();
+        done += nRoots;
+    }
+    return hipSuccess;
+}
+
 } // namespace
 
 void size_pair_stack(FrameParams& P)
@@ -1039,9 +1482,16 @@ bool direct_only(const FrameParams& P)
     return !(P.f.recursive || P.f.glossy || P.f.transparency || (P.f.environment_mapping && P.p.enabled_refl_map));
 }
 
-hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* splitEvents, bool* splitRecorded)
+hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* splitEvents, bool* splitRecorded,
+    unsigned long long* wavefrontNodes)
 {
     if (splitRecorded) *splitRecorded = false;
+    unsigned long long nodesEvaluated = 0;
+    struct Report {
+        unsigned long long* to;
+        unsigned long long& from;
+        ~Report() { if (to) *to = from; }
+    } report { wavefrontNodes, nodesEvaluated };
     FrameParams P = Pin;
     const int rows = P.rowsLocal;
     if (rows <= 0 || P.width <= 0) return hipSuccess;
@@ -1054,8 +1504,12 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     if (P.streamGroup == 4 && uint32_t(P.scene.numPrims) > stream_ref_limit(4)) P.streamGroup = 2;
     const bool fits = uint32_t(P.scene.numPrims) <= stream_ref_limit(P.streamGroup) && P.scene.stackDepth < 64;
     const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P) && fits;
+    // bounce features as wavefront passes (glossy with jittered light sampling would need the depth-first position
+    // of a call on the rand() stream, which a generation-at-a-time evaluation does not have: the general kernel)
+    const bool wavefront = P.wfNodes != nullptr && P.f.accel_structure && !P.scene.hasSpheres && !direct_only(P) && fits && !(P.f.glossy && P.drawsPerHit > 0);
     hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
+        if (wavefront) return prune ? wavefront_pass<true>(P, sBegin, sEnd, lds, stream, nodesEvaluated) : wavefront_pass<false>(P, sBegin, sEnd, lds, stream, nodesEvaluated);
         P.sampleBegin = sBegin;
         P.sampleEnd = sEnd;
         P.logicalBlocks = tiles * uint32_t(sEnd - sBegin);

@@ -325,6 +325,39 @@ def test_small_limits_take_the_spill_and_give_up_paths():
     assert " passed" in out.stdout
 
 
+@pytest.mark.skipif(os.environ.get("RT_TEST_CHILD") == "1", reason="already the child run")
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_bounce_frames_in_both_evaluation_orders(mode):
+    """Frames with mirror reflection, see-through continuation, glossy reflection or the reflection map can be evaluated
+    by the per-lane kernel (one lane walks a pixel sample's whole call tree) or as wavefront passes (one generation of
+    calls per pass).  By default glossy frames take the wavefront passes and the others the per-lane kernel; here every
+    image test runs again in a child process with all bounce frames forced one way (RT_WAVEFRONT=0 / 1)."""
+    env = dict(os.environ, RT_TEST_CHILD="1", RT_WAVEFRONT=mode)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__),
+           "-k", "images_match or glossy or config or wavefront_nodes"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
+
+
+def test_wavefront_nodes_are_reported(lib):
+    """rt_stats.wavefront_nodes says which way a frame went: a glossy frame goes through the wavefront passes unless they
+    are switched off, a direct-lighting frame never does."""
+    g, sc, orc, sh, bvh = setup(lib, "transparent_cornell")
+    lights, n = sc.light_array()
+    W, H = 64, 40
+    _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, glossy=1, transparency=1), rt.default_params(glossy_filter_size=16), W, H)
+    if os.environ.get("RT_WAVEFRONT") == "0":
+        assert st.wavefront_nodes == 0
+    else:
+        assert st.wavefront_nodes >= W * H and st.bounce_rays > 0
+    _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, hard_shadow=1), rt.default_params(), W, H)
+    assert st.wavefront_nodes == 0
+    # mirror recursion: wavefront only when forced
+    _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, recursive=1), rt.default_params(), W, H)
+    assert (st.wavefront_nodes > 0) == (os.environ.get("RT_WAVEFRONT") == "1")
+
+
 def test_headline_frame_at_full_size(lib):
     """The benchmark's frame itself (1920x1080, 16 spp, 16 light samples, 81,920 triangles): bands of it against the
     oracle, plus the size-independent properties — two renders are identical, and the interleaved shares of 8 ranks

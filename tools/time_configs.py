@@ -18,7 +18,7 @@ def run(name, scene, W, H, feats, params, cam):
     for i in range(4):
         _, st = lib.render(bvh, cam, lights, n, feats, params, W, H, 0, H, out=out.data_ptr(), device_ptr=1, stream=0)
         best = st.kernel_ms if best is None else min(best, st.kernel_ms)
-    print(f"{name}: kernel {best:.3f} ms, rays {st.total_rays()/1e6:.2f} M, {st.total_rays()/best/1e3:.0f} Mrays/s", flush=True)
+    print(f"{name}: kernel {best:.3f} ms, rays {st.total_rays()/1e6:.2f} M, {st.total_rays()/best/1e3:.0f} Mrays/s, wavefront nodes {st.wavefront_nodes/1e6:.2f} M", flush=True)
 
 A = o.CAM_A
 run("C1 cornell 512^2 mirror depth 4", "cornell", 512, 512, rt.features(shading=1, recursive=1), rt.default_params(), rt.make_camera(width=512, height=512, **A))
