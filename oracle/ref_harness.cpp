@@ -29,6 +29,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -838,7 +839,30 @@ int main(int argc, char** argv)
         }
         return 0;
     }
-    if (argc < 2) { std::fprintf(stderr, "usage: ref_dump <outdir> [data dir]\n"); return 2; }
+    if (argc >= 2 && std::string(argv[1]) == "--time") {
+        // ref_dump --time [data dir]: wall time of the compiled reference's per-pixel evaluation on one thread (its
+        // lighting code keeps scratch in globals, so the harness does not run it on several), for the ratio between the
+        // reference as it is and the oracle on the same frames.
+        std::filesystem::path dir = argc > 2 ? argv[2] : DATA_DIR;
+        struct Job { const char* name; SceneType type; int W, H; bool soft; int n; };
+        for (const Job& j : { Job { "cornell_para", CornellBoxParallelogramLight, 256, 256, true, 1 }, Job { "cornell_para_4spp", CornellBoxParallelogramLight, 128, 128, true, 2 },
+                 Job { "teapot", Teapot, 128, 128, false, 1 }, Job { "monkey", Monkey, 256, 256, false, 1 } }) {
+            Scene scene = loadScenePrebuilt(j.type, dir);
+            Features f = feat(true, false, false, j.soft, false, false);
+            f.extra.enableMultipleRaysPerPixel = j.n > 1;
+            BvhInterface bvh(&scene, f);
+            RenderOpts o; o.rayMultiplier = j.n;
+            rayMultiplier = j.n;
+            auto t0 = std::chrono::steady_clock::now();
+            auto img = render_image(scene, bvh, CAM_A, j.W, j.H, f, o);
+            double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            rayMultiplier = 1;
+            std::printf("%s %d %d %d %.1f\n", j.name, j.W, j.H, j.n, ms);
+            std::fflush(stdout);
+        }
+        return 0;
+    }
+    if (argc < 2) { std::fprintf(stderr, "usage: ref_dump <outdir> [data dir] | --time [data dir]\n"); return 2; }
     g_out = argv[1];
     std::filesystem::create_directories(g_out);
     std::filesystem::path dataDir = argc > 2 ? argv[2] : DATA_DIR;

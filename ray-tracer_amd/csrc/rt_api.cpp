@@ -90,7 +90,7 @@ struct rt_bvh {
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, wfRays, wfNodes, wfMeta, wfValue, wfHitNode, wfGlossy;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
 };
 
@@ -455,7 +455,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->wfRays, &b->wfNodes, &b->wfMeta, &b->wfValue, &b->wfHitNode, &b->wfGlossy })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->wfRays, &b->wfNodes, &b->wfMeta, &b->wfValue, &b->wfHits, &b->wfHitNode, &b->wfGlossy })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
@@ -664,17 +664,24 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             size_t nodes = 4 * want;
             if (nodes < (size_t(1) << 20)) nodes = size_t(1) << 20;
             if (nodes > (size_t(24) << 20)) nodes = size_t(24) << 20;
+            static const long forcedNodes = [] {
+                const char* e = std::getenv("RT_WAVEFRONT_NODES"); // test knob: a small node buffer makes chunks overflow and split
+                return e ? std::atol(e) : 0L;
+            }();
+            if (forcedNodes > 0) nodes = size_t(forcedNodes < 256 ? 256 : forcedNodes);
             const size_t calls = nodes / size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1) + 64;
             RT_HIP(b->wfRays.reserve(nodes * sizeof(WfRay)));
             RT_HIP(b->wfNodes.reserve(nodes * sizeof(WfNode)));
             RT_HIP(b->wfMeta.reserve(nodes * sizeof(uint32_t)));
             RT_HIP(b->wfValue.reserve(nodes * 12));
+            RT_HIP(b->wfHits.reserve(nodes * sizeof(uint32_t)));
             RT_HIP(b->wfHitNode.reserve(2 * nodes * sizeof(uint32_t))); // one per hit-queue entry
             RT_HIP(b->wfGlossy.reserve(calls * sizeof(WfGlossy)));
             P.wfRays = static_cast<WfRay*>(b->wfRays.ptr);
             P.wfNodes = static_cast<WfNode*>(b->wfNodes.ptr);
             P.wfMeta = static_cast<uint32_t*>(b->wfMeta.ptr);
             P.wfValue = static_cast<float*>(b->wfValue.ptr);
+            P.wfHits = static_cast<uint32_t*>(b->wfHits.ptr);
             P.wfHitNode = static_cast<uint32_t*>(b->wfHitNode.ptr);
             P.wfGlossy = static_cast<WfGlossy*>(b->wfGlossy.ptr);
             P.wfCapacity = uint32_t(nodes);

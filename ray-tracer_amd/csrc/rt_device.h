@@ -114,6 +114,7 @@ struct FrameParams {
     WfNode* wfNodes;
     uint32_t* wfMeta;
     float* wfValue;        // [node][rgb]
+    uint32_t* wfHits;      // [node] calls in the node's subtree that evaluate the lighting
     uint32_t* wfHitNode;   // hit-queue entry -> node whose direct lighting it is
     WfGlossy* wfGlossy;    // glossy calls of the current generation
     uint32_t wfCapacity;   // nodes

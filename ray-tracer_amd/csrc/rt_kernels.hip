@@ -952,7 +952,8 @@ __global__ void __launch_bounds__(BLOCK) k_bloom(const float* __restrict__ src, 
 //   k_wf_combine  values bottom-up, one generation per launch, with the reference's operations in its order; the
 //                 roots write the pixel samples.
 // A call's random draws do not depend on the evaluation order: light jitter is indexed from the node's randBase
-// (chains of single children advance it like the recursion does), glossy deviates from a hash of the reflection ray.
+// (its depth-first position on the rand() stream, see k_wf_count / k_wf_index), glossy deviates from a hash of the
+// reflection ray.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wf_pixel(const FrameParams& P, uint32_t work, uint32_t nPix, size_t& pix, int& sidx, int& x, int& y)
 {
@@ -1080,6 +1081,9 @@ __global__ void __launch_bounds__(WAVE) k_wf_trace(const FrameParams P)
                 if (lane == leader) P.queueCounters[Q_WF_OVERFLOW] = 1ull;
             }
             glossyAt = uint32_t(gb) + lanes_below(glossyVotes);
+            // A list entry that was reserved but cannot be used (this wave's nodes or the list itself did not fit) must
+            // not keep what an earlier chunk left there: k_wf_spawn runs before the host learns of the overflow.
+            if (!fitsNodes && kind == WF_GLOSSY && nChildren > 0 && glossyAt < P.wfGlossyCapacity) P.wfGlossy[glossyAt].node = 0xffffffffu;
         }
         // ---- hit queue entries of the calls whose value needs Lo (the queue holds an entry per root and per node)
         const unsigned long long loVotes = __ballot(wantsLo);
@@ -1171,15 +1175,19 @@ __global__ void __launch_bounds__(WAVE) k_wf_trace(const FrameParams P)
 __global__ void __launch_bounds__(BLOCK) k_wf_spawn(const FrameParams P)
 {
     const uint32_t filter = uint32_t(P.p.glossy_filter_size);
-    const unsigned long long calls = P.queueCounters[Q_WF_GLOSSY];
+    // (after an overflow the counter can exceed the list, and entries of waves whose nodes did not fit are void)
+    unsigned long long calls = P.queueCounters[Q_WF_GLOSSY];
+    if (calls > (unsigned long long)P.wfGlossyCapacity) calls = P.wfGlossyCapacity;
     const unsigned long long n = calls * filter;
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     for (unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * BLOCK) {
         const WfGlossy g = P.wfGlossy[i / filter];
         const uint32_t k = uint32_t(i % filter);
+        if (g.node >= P.wfCapacity) continue; // void entry
         const WfNode& parent = P.wfNodes[g.node];
         const uint32_t parentMeta = P.wfMeta[g.node];
         const uint32_t child = parent.firstChild + k;
+        if (child >= P.wfCapacity) continue;
         const uint32_t work = P.wfRays[g.node].work;
         size_t pix;
         int sidx, x, y;
@@ -1211,6 +1219,51 @@ __global__ void __launch_bounds__(BLOCK) k_wf_spawn(const FrameParams P)
             nd.randBase = parent.randBase + uint32_t(P.drawsPerHit);
         } else {
             P.wfMeta[child] = wf_meta(WF_DEAD, 0, 0);
+        }
+    }
+}
+
+// Position of every call on the rand() stream when calls fan out (glossy reflection) AND the lights are jittered: the
+// reference draws in the order its recursion runs, so a call's first draw comes after the draws of everything the
+// recursion evaluated before it — its ancestors' lighting and the whole subtrees of its earlier siblings.  The shape
+// of the tree does not depend on those draws (they only jitter light samples), so it is expanded first; then
+//   k_wf_count  bottom-up: calls in every node's subtree that evaluate the lighting (every call that hit something);
+//   k_wf_index  top-down: a parent hands each child the stream position after its own draws and its earlier
+//               children's subtrees.
+// Chains of single children need neither: k_wf_trace gives the child its position directly.
+__global__ void __launch_bounds__(BLOCK) k_wf_count(const FrameParams P)
+{
+    const uint32_t n = P.wfEnd - P.wfBegin;
+    const uint32_t filter = uint32_t(P.p.glossy_filter_size);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t node = P.wfBegin + i;
+        const uint32_t meta = P.wfMeta[node];
+        if (meta & WF_ROOT) continue; // nothing asks for a pixel sample's own total
+        const uint32_t kind = wf_kind(meta);
+        uint32_t hits = (kind == WF_DEAD || kind == WF_MISS || kind == WF_PENDING) ? 0u : 1u;
+        if (kind == WF_BLEND || kind == WF_MIRROR) hits += P.wfHits[P.wfNodes[node].firstChild];
+        else if (kind == WF_GLOSSY)
+            for (uint32_t k = 0; k < filter; k++) hits += P.wfHits[P.wfNodes[node].firstChild + k];
+        P.wfHits[node] = hits;
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_wf_index(const FrameParams P)
+{
+    const uint32_t n = P.wfEnd - P.wfBegin;
+    const uint32_t filter = uint32_t(P.p.glossy_filter_size);
+    const uint32_t draws = uint32_t(P.drawsPerHit);
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t node = P.wfBegin + i;
+        const uint32_t meta = P.wfMeta[node];
+        const uint32_t kind = wf_kind(meta);
+        if (((meta & WF_ROOT) != 0u) != (P.wfRootsTurn != 0) || (kind != WF_BLEND && kind != WF_MIRROR && kind != WF_GLOSSY)) continue;
+        const WfNode& nd = P.wfNodes[node];
+        uint32_t at = nd.randBase + draws; // this call's own lighting draws come first (render.cpp:25)
+        const uint32_t children = kind == WF_GLOSSY ? filter : 1u;
+        for (uint32_t k = 0; k < children; k++) {
+            const uint32_t c = nd.firstChild + k;
+            P.wfNodes[c].randBase = at;
+            at += draws * P.wfHits[c];
         }
     }
 }
@@ -1437,6 +1490,24 @@ hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipS
             chunk = nRoots / 2u;
             continue;
         }
+        if (P.f.glossy && P.drawsPerHit > 0 && gens.size() > 1) {
+            auto blocks_for = [](uint32_t n) { const uint32_t b = (n + BLOCK - 1) / BLOCK; return dim3(b < 256u * 16u ? b : 256u * 16u); };
+            for (size_t g = gens.size() - 1; g-- > 0;) { // subtree totals, deepest generation first
+                P.wfBegin = gens[g];
+                P.wfEnd = gens[g + 1];
+                hipLaunchKernelGGL(k_wf_count, blocks_for(P.wfEnd - P.wfBegin), dim3(BLOCK), 0, stream, P);
+            }
+            for (size_t g = 0; g + 1 < gens.size(); g++) { // stream positions, top-down; the pixel samples' own nodes first
+                P.wfBegin = gens[g];
+                P.wfEnd = gens[g + 1];
+                if (g == 0) {
+                    P.wfRootsTurn = 1;
+                    hipLaunchKernelGGL(k_wf_index, blocks_for(P.wfEnd - P.wfBegin), dim3(BLOCK), 0, stream, P);
+                    P.wfRootsTurn = 0;
+                }
+                hipLaunchKernelGGL(k_wf_index, blocks_for(P.wfEnd - P.wfBegin), dim3(BLOCK), 0, stream, P);
+            }
+        }
         // direct lighting of every call that needs it, all generations at once
         P.wfLighting = 1;
         if (P.shadowSamplesPerHit > 0) {
@@ -1504,9 +1575,8 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     if (P.streamGroup == 4 && uint32_t(P.scene.numPrims) > stream_ref_limit(4)) P.streamGroup = 2;
     const bool fits = uint32_t(P.scene.numPrims) <= stream_ref_limit(P.streamGroup) && P.scene.stackDepth < 64;
     const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P) && fits;
-    // bounce features as wavefront passes (glossy with jittered light sampling would need the depth-first position
-    // of a call on the rand() stream, which a generation-at-a-time evaluation does not have: the general kernel)
-    const bool wavefront = P.wfNodes != nullptr && P.f.accel_structure && !P.scene.hasSpheres && !direct_only(P) && fits && !(P.f.glossy && P.drawsPerHit > 0);
+    // bounce features as wavefront passes
+    const bool wavefront = P.wfNodes != nullptr && P.f.accel_structure && !P.scene.hasSpheres && !direct_only(P) && fits;
     hipError_t e;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         if (wavefront) return prune ? wavefront_pass<true>(P, sBegin, sEnd, lds, stream, nodesEvaluated) : wavefront_pass<false>(P, sBegin, sEnd, lds, stream, nodesEvaluated);
