@@ -663,6 +663,16 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && features->glossy))) {
             size_t nodes = 4 * want;
             if (nodes < (size_t(1) << 20)) nodes = size_t(1) << 20;
+            if (features->glossy) {
+                // room for the largest call tree one pixel sample can have (filter^depth glossy samples at the deepest level),
+                // so that a chunk of a single sample always fits
+                size_t worst = 1, level = 1;
+                for (int d = 0; d < params->ray_depth && worst < (size_t(24) << 20); d++) {
+                    level *= size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1);
+                    worst += level;
+                }
+                if (nodes < 2 * worst) nodes = 2 * worst; // (see-through continuations between the glossy levels add a few each)
+            }
             if (nodes > (size_t(24) << 20)) nodes = size_t(24) << 20;
             static const long forcedNodes = [] {
                 const char* e = std::getenv("RT_WAVEFRONT_NODES"); // test knob: a small node buffer makes chunks overflow and split

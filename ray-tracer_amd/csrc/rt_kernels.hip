@@ -1532,6 +1532,11 @@ hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipS
         if ((e = hipGetLastError()) != hipSuccess) return e;
         nodesEvaluated += (unsigned long long)nRoots + gens.back();
         done += nRoots;
+        // next chunk: as many roots as fill 60 % of the node buffer at the node-per-root rate just seen (a chunk that had
+        // to be halved because of a few heavy samples grows back afterwards)
+        const double perRoot = double(gens.back()) / double(nRoots);
+        const double fit = 0.6 * double(P.wfCapacity) / (perRoot > 1e-3 ? perRoot : 1e-3);
+        chunk = fit >= double(P.wfCapacity) ? P.wfCapacity : (fit < 1.0 ? 1ull : (unsigned long long)fit);
     }
     return hipSuccess;
 }

@@ -369,10 +369,10 @@ def test_bounce_frames_in_both_evaluation_orders(mode):
 
 @pytest.mark.skipif(os.environ.get("RT_TEST_CHILD") == "1", reason="already the child run")
 def test_wavefront_chunks_that_overflow_are_split():
-    """A node buffer of 3,000 nodes (RT_WAVEFRONT_NODES) cannot hold the call trees of a chunk of pixel samples once glossy
+    """A node buffer of 6,000 nodes (RT_WAVEFRONT_NODES) cannot hold the call trees of a chunk of pixel samples once glossy
     calls fan out 64-fold: chunks are abandoned and rendered again in halves until they fit.  The images (and the ray
     counts, which must not keep anything of an abandoned attempt) are the same."""
-    env = dict(os.environ, RT_TEST_CHILD="1", RT_WAVEFRONT="1", RT_WAVEFRONT_NODES="3000")
+    env = dict(os.environ, RT_TEST_CHILD="1", RT_WAVEFRONT="1", RT_WAVEFRONT_NODES="6000")
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__),
            "-k", "glossy or config_feature_sets or config1 or (images_match and (recursive or transparency or sky_refl))"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
