@@ -99,6 +99,7 @@ struct FrameParams {
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
                                        // primary pass: the camera rays (sample * pixels + pixel) that gave up
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
+    int32_t primarySmallPass;          // a pass with fewer tiles per resident wave than this runs with a budget of 32
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
     int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features
