@@ -36,7 +36,7 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak
 L2_PEAK_GBS = 34500.0      # MI355X aggregate L2 bandwidth (8 XCDs)
 CPU_ROW_STEP = 12          # the CPU leg renders every 12th row of the frame
 # the kernels of one frame of the headline workload as rocprofv3 names them (timed variants: test counting off)
-FRAME_KERNELS = ["k_primary<true, false>", "k_stream<false, true>", "k_closest<true, false>", "k_cull", "k_stream<false, false>", "k_shade", "k_resolve"]
+FRAME_KERNELS = ["k_primary<true, false>", "k_stream<false, true, 1>", "k_closest<true, false>", "k_cull", "k_stream<false, false, 2>", "k_shade", "k_resolve"]
 CAMERA = dict(fov_deg=50.0, distance=3.0, look_at=(0.0, 0.0, 0.0), rot_deg=(20.0, 20.0, 0.0))  # reference src/config.h:16-21
 
 
@@ -210,8 +210,8 @@ def main():
                           "shadow_box_tests": cst.shadow_box_tests, "shadow_triangle_tests": cst.shadow_triangle_tests,
                           "box_tests": cst.box_tests, "triangle_tests": cst.triangle_tests, "rays": cst.total_rays()}
         if have_split:
-            dom_name = "k_stream<false, false> (shadow pass)"
-            dom_key = "k_stream<false, false>"
+            dom_name = "k_stream<false, false, 2> (shadow pass)"
+            dom_key = "k_stream<false, false, 2>"
             alg_flops = 27 * ref_counts["shadow_box_tests"] + 150 * ref_counts["shadow_triangle_tests"]
             alg_bytes = 44 * ref_counts["shadow_rays"] + 32 * ref_counts["shadow_box_tests"] + 36 * ref_counts["shadow_triangle_tests"]
             own_flops = 27 * cst.shadow_box_tests + 150 * cst.shadow_triangle_tests

@@ -41,7 +41,7 @@ for k in per_kernel:
                         ("lds_bank_conflict_cycles", lds_conflict), ("lds_active_cycles", lds_active)):
         if k in table:
             per_kernel[k][name] = table[k]
-frame = ["k_primary<true, false>", "k_stream<false, true>", "k_closest<true, false>", "k_cull", "k_stream<false, false>", "k_shade", "k_resolve"]
+frame = ["k_primary<true, false>", "k_stream<false, true, 1>", "k_closest<true, false>", "k_cull", "k_stream<false, false, 2>", "k_shade", "k_resolve"]
 doc = {
     "source": "profiles/%s/summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, of `python3 bench.py "
               "--steps 3 --warmup 1 --no-cpu-baseline` on one MI355X; per-dispatch averages" % tag,
@@ -50,8 +50,8 @@ doc = {
     "units": "FETCH_SIZE and WRITE_SIZE are reported in KiB; bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-byte read "
              "requests as 64 bytes) + WRITE_SIZE x 1024",
     "per_kernel": per_kernel,
-    "dominant_kernel": "k_stream<false, false>",
-    "dominant_kernel_hbm_bytes_per_launch": per_kernel["k_stream<false, false>"]["hbm_bytes_per_launch"],
+    "dominant_kernel": "k_stream<false, false, 2>",
+    "dominant_kernel_hbm_bytes_per_launch": per_kernel["k_stream<false, false, 2>"]["hbm_bytes_per_launch"],
     "hbm_bytes_per_frame": sum(per_kernel[k]["hbm_bytes_per_launch"] for k in frame if k in per_kernel),
 }
 json.dump(doc, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)

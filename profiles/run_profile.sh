@@ -10,7 +10,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
 for p in $PASSES; do
   case $p in
     trace) ARGS="--kernel-trace --stats" ;;
