@@ -1274,34 +1274,64 @@ __global__ void __launch_bounds__(BLOCK) k_wf_index(const FrameParams P)
 __global__ void __launch_bounds__(BLOCK) k_wf_combine(const FrameParams P)
 {
     const uint32_t n = P.wfEnd - P.wfBegin;
+    const uint32_t rounded = (n + 63u) & ~63u; // whole waves stay in the loop together (the glossy sums are a wave's job)
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
-    const int filter = P.p.glossy_filter_size;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+    const uint32_t filter = uint32_t(P.p.glossy_filter_size);
+    const int lane = int(threadIdx.x) & 63;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < rounded; i += gridDim.x * BLOCK) {
         const uint32_t node = P.wfBegin + i;
-        const uint32_t meta = P.wfMeta[node];
-        const uint32_t kind = wf_kind(meta);
-        const bool root = (meta & WF_ROOT) != 0u;
-        // (the value of a call that ends at its hit or miss was written where it was found: nothing to combine)
-        if ((kind != WF_BLEND && kind != WF_MIRROR && kind != WF_GLOSSY) || root != (P.wfRootsTurn != 0)) continue;
-        const WfNode& nd = P.wfNodes[node];
-        vec3 result;
-        if (kind == WF_BLEND) {
-            const vec3 child = load3(P.wfValue + 3 * size_t(nd.firstChild));
-            result = nd.a * load3(nd.coef) + (1.0f - nd.a) * child; // render.cpp:43
-        } else if (kind == WF_MIRROR) {
-            result = load3(nd.coef) * load3(P.wfValue + 3 * size_t(nd.firstChild)); // render.cpp:61
-        } else {
-            vec3 sum = splat3(0.0f);
-            for (int k = 0; k < filter; k++) {
-                const uint32_t c = nd.firstChild + uint32_t(k);
-                if (wf_kind(P.wfMeta[c]) != WF_DEAD) sum = sum + load3(P.wfValue + 3 * size_t(c));
-            }
-            result = load3(nd.coef) * sum / float(filter); // render.cpp:59
+        uint32_t kind = WF_DEAD;
+        bool root = false;
+        if (i < n) {
+            const uint32_t meta = P.wfMeta[node];
+            root = (meta & WF_ROOT) != 0u;
+            // (the value of a call that ends at its hit or miss was written where it was found: nothing to combine)
+            if (root == (P.wfRootsTurn != 0)) kind = wf_kind(meta);
         }
+        vec3 result = splat3(0.0f);
+        uint32_t firstChild = 0;
+        vec3 coef = splat3(0.0f);
+        if (kind == WF_BLEND || kind == WF_MIRROR || kind == WF_GLOSSY) {
+            const WfNode& nd = P.wfNodes[node];
+            firstChild = nd.firstChild;
+            coef = load3(nd.coef);
+            if (kind == WF_BLEND) result = nd.a * coef + (1.0f - nd.a) * load3(P.wfValue + 3 * size_t(firstChild)); // render.cpp:43
+            else if (kind == WF_MIRROR) result = coef * load3(P.wfValue + 3 * size_t(firstChild));                   // render.cpp:61
+        }
+        // Glossy calls: the children's values are summed in sample order like the reference does (render.cpp:56-58).  A
+        // lane walking its own 64 children would touch 64 scattered cache lines per step of the wave; instead the wave
+        // takes the calls of its lanes one at a time, loads a call's children with one coalesced read (child k by lane
+        // k) and runs the ordered sum on values handed round from the lanes' registers.
+        unsigned long long todo = __ballot(kind == WF_GLOSSY);
+        while (todo) {
+            const int owner = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t first = uint32_t(__builtin_amdgcn_readlane(int(firstChild), owner));
+            vec3 sum = splat3(0.0f);
+            for (uint32_t base = 0; base < filter; base += 64u) {
+                const uint32_t k = base + uint32_t(lane);
+                bool alive = false;
+                vec3 v = splat3(0.0f);
+                if (k < filter) {
+                    alive = wf_kind(P.wfMeta[first + k]) != WF_DEAD;
+                    if (alive) v = load3(P.wfValue + 3 * size_t(first + k));
+                }
+                const unsigned long long live = __ballot(alive);
+                const uint32_t count = filter - base < 64u ? filter - base : 64u;
+                for (uint32_t j = 0; j < count; j++) {
+                    if (!((live >> j) & 1ull)) continue;
+                    sum = sum + make3(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.x), int(j))),
+                                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.y), int(j))),
+                                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.z), int(j))));
+                }
+            }
+            if (lane == owner) result = coef * sum / float(filter); // render.cpp:59
+        }
+        if (kind != WF_BLEND && kind != WF_MIRROR && kind != WF_GLOSSY) continue;
         if (root) {
             size_t pix;
             int sidx, x, y;
-            wf_pixel(P, P.wfRays[P.wfBegin + i].work, nPix, pix, sidx, x, y);
+            wf_pixel(P, P.wfRays[node].work, nPix, pix, sidx, x, y);
             float* out = sample_slot(P, pix, sidx);
             out[0] = result.x; out[1] = result.y; out[2] = result.z;
         } else {
