@@ -1,9 +1,11 @@
 // Command-line renderer: the reference's "command_line_rendering" mode (reference src/main.cpp:499-556).
-//   rt_cli <config.toml> [--gpus N] [--print-config]
+//   rt_cli <config.toml> [--gpus N] [--tiles T] [--print-config]
 // Reads the configuration, prints it, loads the scene (a prebuilt one, or an OBJ file with the configured lights),
 // builds the hierarchy and renders one bitmap per configured camera into the output directory, named
 // <scene>_<start time>_cam_<index>.bmp like the reference's.  The reference gives every camera a CPU thread; here
 // the cameras are dealt round-robin to N GPUs (default 1), one host thread and one copy of the hierarchy per GPU.
+// With --tiles T (> 1) the cameras are rendered one after the other instead, each frame's rows dealt in blocks of 16 to T
+// shares spread over the N GPUs (renderRayTracingTiled: the reference's row parallelism across GPUs; T may exceed N).
 // --print-config stops after printing (used by the tests).  The interactive window of the reference is not part
 // of this program: a configuration with command_line_rendering = false is refused.
 #include "rt_config.h"
@@ -13,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -21,16 +24,17 @@ using namespace rtamd;
 int main(int argc, char** argv)
 {
     const char* configFile = nullptr;
-    int gpus = 1;
+    int gpus = 1, tiles = 1;
     bool printOnly = false;
     for (int i = 1; i < argc; i++) {
         if (std::strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) gpus = std::atoi(argv[++i]);
+        else if (std::strcmp(argv[i], "--tiles") == 0 && i + 1 < argc) tiles = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--print-config") == 0) printOnly = true;
         else if (!configFile) configFile = argv[i];
         else configFile = "";
     }
-    if (!configFile || !*configFile || gpus < 1) {
-        std::fprintf(stderr, "usage: rt_cli <config.toml> [--gpus N] [--print-config]\n");
+    if (!configFile || !*configFile || gpus < 1 || tiles < 1) {
+        std::fprintf(stderr, "usage: rt_cli <config.toml> [--gpus N] [--tiles T] [--print-config]\n");
         return 2;
     }
     Config config;
@@ -102,9 +106,41 @@ int main(int argc, char** argv)
             screen.writeBitmapToFile(file);
         }
     };
-    std::vector<std::thread> workers;
-    for (int g = 0; g < gpus; g++) workers.emplace_back(worker, g);
-    for (std::thread& w : workers) w.join();
+    if (tiles > 1) {
+        // one hierarchy per GPU (built by a thread that has selected it), every camera's frame dealt to `tiles` shares
+        std::vector<std::unique_ptr<BvhInterface>> bvhs;
+        bvhs.resize(size_t(gpus));
+        std::vector<std::thread> builders;
+        for (int g = 0; g < gpus; g++)
+            builders.emplace_back([&, g] {
+                if (rt_init(g) != RT_OK) {
+                    std::lock_guard<std::mutex> lock(printLock);
+                    std::cerr << "GPU " << g << ": " << rt_last_error() << std::endl;
+                    failed = true;
+                    return;
+                }
+                bvhs[size_t(g)] = std::make_unique<BvhInterface>(&scene, config.features);
+            });
+        for (std::thread& b : builders) b.join();
+        if (failed) return 1;
+        std::vector<RenderShare> shares;
+        for (int t = 0; t < tiles; t++) shares.push_back(RenderShare { bvhs[size_t(t % gpus)].get(), t % gpus });
+        for (size_t index = 0; index < config.cameras.size(); index++) {
+            const CameraConfig& c = config.cameras[index];
+            Screen screen { config.windowSize, false };
+            screen.clear(vec3(0.0f));
+            Trackball camera { float(config.windowSize.x) / float(config.windowSize.y), c.fieldOfView * rad, vec3(0.0f), c.distanceFromLookAt };
+            camera.setCamera(c.lookAt, vec3(c.rotation.x * rad, c.rotation.y * rad, c.rotation.z * rad), c.distanceFromLookAt);
+            renderRayTracingTiled(scene, camera, shares, screen, config.features);
+            const std::filesystem::path file = config.outputDir / (sceneName + "_" + startTime + "_cam_" + std::to_string(index) + ".bmp");
+            std::cout << "Image " << index << " saved to " << file.string() << std::endl;
+            screen.writeBitmapToFile(file);
+        }
+    } else {
+        std::vector<std::thread> workers;
+        for (int g = 0; g < gpus; g++) workers.emplace_back(worker, g);
+        for (std::thread& w : workers) w.join();
+    }
     const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - start).count();
     std::cout << "Rendering took " << ms << " ms, " << config.cameras.size() << " images rendered." << std::endl;
     return failed ? 1 : 0;

@@ -1,4 +1,6 @@
 #include "rt_facade.h"
+#include <string>
+#include <thread>
 
 #include <algorithm>
 #include <cmath>
@@ -337,6 +339,52 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
     g_lastStats = stats;
     if (features.extra.enableBloomEffect && rt_bloom(out, res.x, res.y, &p, 0, nullptr) != RT_OK)
         std::fprintf(stderr, "renderRayTracing (bloom): %s\n", rt_last_error());
+}
+
+void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const std::vector<RenderShare>& shares, Screen& screen, const Features& features)
+{
+    const int n = int(shares.size());
+    if (n == 0) return;
+    const ivec2 res = screen.resolution();
+    const rt_features f = to_abi(features);
+    const rt_params p = snapshot_params();
+    const rt_camera cam = camera.abi();
+    const std::vector<rt_light> lights = to_abi(scene);
+    constexpr int rowBlock = 16;
+    const int nBlocks = (res.y + rowBlock - 1) / rowBlock;
+    std::vector<std::vector<float>> parts { size_t(n) };
+    std::vector<std::string> errors { size_t(n) };
+    std::vector<std::thread> threads;
+    for (int i = 0; i < n; i++)
+        threads.emplace_back([&, i] {
+            if (!shares[size_t(i)].bvh || !shares[size_t(i)].bvh->handle()) return;
+            int rows = 0;
+            for (int b = i; b < nBlocks; b += n) rows += std::min(res.y, (b + 1) * rowBlock) - b * rowBlock;
+            parts[size_t(i)].assign(size_t(rows) * size_t(res.x) * 3, 0.0f);
+            if (rows == 0) return;
+            if (rt_init(shares[size_t(i)].device) != RT_OK ||
+                rt_render_blocks(shares[size_t(i)].bvh->handle(), &cam, lights.data(), int32_t(lights.size()), &f, &p, res.x, res.y, rowBlock, i, n,
+                    parts[size_t(i)].data(), 0, nullptr, nullptr) != RT_OK)
+                errors[size_t(i)] = rt_last_error(); // (the error text belongs to the thread that made the call)
+        });
+    for (std::thread& t : threads) t.join();
+    for (const std::string& e : errors)
+        if (!e.empty()) {
+            std::fprintf(stderr, "renderRayTracingTiled: %s\n", e.c_str());
+            return;
+        }
+    float* out = reinterpret_cast<float*>(screen.pixels().data());
+    for (int i = 0; i < n; i++) {
+        size_t at = 0;
+        for (int b = i; b < nBlocks; b += n) {
+            const int top = b * rowBlock, bottom = std::min(res.y, top + rowBlock);
+            const size_t count = size_t(bottom - top) * size_t(res.x) * 3;
+            std::memcpy(out + size_t(top) * size_t(res.x) * 3, parts[size_t(i)].data() + at, count * sizeof(float));
+            at += count;
+        }
+    }
+    if (features.extra.enableBloomEffect && rt_bloom(out, res.x, res.y, &p, 0, nullptr) != RT_OK)
+        std::fprintf(stderr, "renderRayTracingTiled (bloom): %s\n", rt_last_error());
 }
 
 const rt_stats& lastRenderStats() { return g_lastStats; }

@@ -200,6 +200,18 @@ private:
 // the device path is reported on stderr and leaves the screen untouched (the reference has no error path).
 void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInterface& bvh, Screen& screen, const Features& features);
 
+// renderRayTracing with the frame's rows dealt to several hierarchies, normally one per GPU: the reference hands rows
+// to OpenMP threads (src/render.cpp:86-89); here the frame's blocks of 16 Screen rows are dealt round-robin to
+// `shares.size()` shares, share i is rendered by a host thread of its own with one rt_render_blocks call on
+// shares[i].bvh after rt_init(shares[i].device), the shares are put together in `screen` and bloom runs on the
+// assembled frame.  Every hierarchy must have been built from `scene`; several shares may use the same hierarchy
+// (they then take turns on it).  Random streams are keyed by pixel, so the frame does not depend on the shares.
+struct RenderShare {
+    const BvhInterface* bvh;
+    int device;
+};
+void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const std::vector<RenderShare>& shares, Screen& screen, const Features& features);
+
 // Last rt_stats of renderRayTracing on this thread (no counterpart; the reference only prints wall time).
 const rt_stats& lastRenderStats();
 

@@ -106,8 +106,10 @@ def read_bmp(path, w, h):
 
 
 @pytest.mark.gpu
-def test_prebuilt_scene_through_the_program_matches_the_golden_image(tmp_path):
-    """Scene 8 (spheres: no data files), the golden frame size and camera, shading + hard shadows."""
+@pytest.mark.parametrize("extra", [[], ["--tiles", "3"]], ids=["whole-frames", "row-tiles"])
+def test_prebuilt_scene_through_the_program_matches_the_golden_image(tmp_path, extra):
+    """Scene 8 (spheres: no data files), the golden frame size and camera, shading + hard shadows; once a camera per
+    call, once every frame dealt in 16-row blocks to three shares (the multi-GPU row tiling, here on one GPU)."""
     W, H = o.SIZE_A
     out = tmp_path / "out"
     cfg = tmp_path / "spheres.toml"
@@ -134,9 +136,9 @@ distance_from_look_at = 5.0
 look_at = [0.0, 0.0, 6.0]
 rotation = [0.0, 180.0, 0.0]
 """)
-    res = run_cli([str(cfg)])
+    res = run_cli([str(cfg)] + extra)
     assert res.returncode == 0, res.stderr
-    assert "renderRayTracing:" not in res.stderr
+    assert "renderRayTracing" not in res.stderr
     assert "2 images rendered." in res.stdout and "SceneType::Spheres" in res.stdout
     files = sorted(glob.glob(str(out / "spheres_*_cam_*.bmp")))
     assert len(files) == 2 and files[0].endswith("_cam_0.bmp")
