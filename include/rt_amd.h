@@ -192,6 +192,13 @@ void rt_scene_destroy(rt_scene* scene);
 /* BVH build + flatten + upload: replaces BoundingVolumeHierarchy's constructor
  * (src/bounding_volume_hierarchy.cpp:41-208).  The scene must outlive the bvh. */
 rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** out);
+/* The same hierarchy, node for node, with the per-level sorts of the reference's median-split build
+ * (src/bounding_volume_hierarchy.cpp:192-197) done on the current GPU as segmented radix sorts; boxes and node
+ * numbering are still made on the host.  Falls back to rt_bvh_build where the result could depend on how std::sort
+ * orders equal keys (equal centroid coordinates meeting at a cut), for the SAH variant, and when max_level would cut
+ * the tree short.  rt_bvh_device_sorted tells which way a hierarchy was built (1 = sorts on the GPU). */
+rt_status rt_bvh_build_device(rt_scene* scene, const rt_bvh_options* options, rt_bvh** out);
+int32_t rt_bvh_device_sorted(const rt_bvh* bvh);
 void rt_bvh_destroy(rt_bvh* bvh);
 int32_t rt_bvh_num_levels(const rt_bvh* bvh); /* BvhInterface::numLevels */
 int32_t rt_bvh_num_leaves(const rt_bvh* bvh); /* BvhInterface::numLeaves */

@@ -339,6 +339,8 @@ class Library:
         lib.rt_scene_destroy.argtypes = [C.c_void_p]
         lib.rt_scene_destroy.restype = None
         lib.rt_bvh_build.argtypes = [C.c_void_p, C.POINTER(BvhOptions), C.POINTER(C.c_void_p)]
+        lib.rt_bvh_build_device.argtypes = [C.c_void_p, C.POINTER(BvhOptions), C.POINTER(C.c_void_p)]
+        lib.rt_bvh_device_sorted.argtypes = [C.c_void_p]
         lib.rt_bvh_destroy.argtypes = [C.c_void_p]
         lib.rt_bvh_destroy.restype = None
         for fn in ("rt_bvh_num_levels", "rt_bvh_num_leaves", "rt_bvh_num_nodes", "rt_bvh_num_prim_refs"):
@@ -374,6 +376,14 @@ class Library:
         opt = BvhOptions(int(sah), max_level, sah_bins)
         self.check(self.lib.rt_bvh_build(scene_handle, C.byref(opt), C.byref(h)))
         return h
+
+    def bvh_build_device(self, scene_handle, sah=False, max_level=32, sah_bins=64):
+        """rt_bvh_build_device: the same hierarchy with the per-level sorts on the GPU (falls back to the host sorts
+        where equal keys meet at a cut); returns (handle, sorted_on_device)."""
+        h = C.c_void_p()
+        opt = BvhOptions(int(sah), max_level, sah_bins)
+        self.check(self.lib.rt_bvh_build_device(scene_handle, C.byref(opt), C.byref(h)))
+        return h, bool(self.lib.rt_bvh_device_sorted(h))
 
     def bvh_export(self, bvh):
         nn = self.lib.rt_bvh_num_nodes(bvh)

@@ -92,6 +92,7 @@ struct Builder {
     bool sah;
     int spawnLevels; // subtrees above this level are built by a thread of their own
     size_t spawnMinimum;
+    bool presorted = false; // `order` already is the final leaf order (per-level sorts done elsewhere): ranges are only cut
 
     static Bounds empty() { return { splat3(FLT_MAX), splat3(-FLT_MAX) }; }
     static void grow(Bounds& b, const PrimBounds& p)
@@ -231,7 +232,7 @@ struct Builder {
         if (sah) {
             split = sahSplit(first, last, box);
         } else {
-            sortAxis(first, last, level % 3);
+            if (!presorted) sortAxis(first, last, level % 3);
             split = count / 2;
         }
         out.nodes.push_back(rec);
@@ -275,6 +276,55 @@ struct Builder {
 
 void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out)
 {
+    build_bvh(scene, opt, out, nullptr);
+}
+
+void reference_sort(int* indices, size_t count, const float* centroids, int axis)
+{
+    // the same element type, comparator and std::sort instantiation as Builder::sortAxis: same moves on equal keys
+    struct Keyed {
+        float key;
+        int index;
+    };
+    std::vector<Keyed> keyed(count);
+    for (size_t i = 0; i < count; i++) keyed[i] = { centroids[size_t(indices[i]) * 3 + size_t(axis)], indices[i] };
+    std::sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
+    for (size_t i = 0; i < count; i++) indices[i] = keyed[i].index;
+}
+
+bool device_sort_applies(const HostScene& scene, const rt_bvh_options& opt)
+{
+    size_t total = scene.spheres.size();
+    for (const HostMesh& m : scene.meshes) total += m.triangles.size() / 3;
+    // one primitive per leaf is what makes the node ranges a function of the count alone: the level limit must not
+    // cut the tree short; the SAH variant chooses its cuts from the data
+    int levels = 0;
+    while ((size_t(1) << levels) < total) levels++;
+    return !opt.sah_binning && total >= 2 && levels <= opt.max_level;
+}
+
+void primitive_centroids(const HostScene& scene, std::vector<float>& centroids)
+{
+    centroids.clear();
+    for (const HostMesh& mesh : scene.meshes)
+        for (size_t t = 0; t < mesh.triangles.size() / 3; t++) {
+            const vec3 a = load3(&mesh.vertices[size_t(mesh.triangles[3 * t]) * 8]);
+            const vec3 b = load3(&mesh.vertices[size_t(mesh.triangles[3 * t + 1]) * 8]);
+            const vec3 c = load3(&mesh.vertices[size_t(mesh.triangles[3 * t + 2]) * 8]);
+            const vec3 sum = (a + b) + c; // the same operations as the primitive list below
+            centroids.push_back(sum.x / 3.0f);
+            centroids.push_back(sum.y / 3.0f);
+            centroids.push_back(sum.z / 3.0f);
+        }
+    for (const rt_sphere_desc& sp : scene.spheres) {
+        centroids.push_back(sp.center[0]);
+        centroids.push_back(sp.center[1]);
+        centroids.push_back(sp.center[2]);
+    }
+}
+
+void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out, const std::vector<int>* leafOrder)
+{
     out = HostBvh {};
     std::vector<PrimBounds> prims;
     size_t total = scene.spheres.size();
@@ -309,6 +359,10 @@ void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out)
     while ((1u << (spawnLevels + 1)) <= threads) spawnLevels++;
     Builder b { prims, std::vector<int>(prims.size()), opt.max_level, opt.sah_bins, opt.sah_binning != 0, spawnLevels, size_t(4096) };
     std::iota(b.order.begin(), b.order.end(), 0);
+    if (leafOrder && leafOrder->size() == prims.size()) {
+        b.order = *leafOrder;
+        b.presorted = true;
+    }
     Subtree tree;
     tree.nodes.reserve(prims.size() * 2 + 1);
     tree.prims.reserve(prims.size());

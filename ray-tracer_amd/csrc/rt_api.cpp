@@ -86,6 +86,7 @@ struct rt_bvh {
     HostBvh host;
     FlatBvh flat; // host image of the device tables; dropped after the upload
     bool uploaded = false;
+    bool deviceSorted = false; // the per-level sorts of the build ran on the GPU
     DevBuf nodes, prims, attrs, primOrder;
     SceneView view {};
     // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
@@ -451,6 +452,47 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
     *out = b;
     return RT_OK;
 }
+
+rt_status rt_bvh_build_device(rt_scene* scene, const rt_bvh_options* options, rt_bvh** out)
+{
+    if (!scene || !out) return fail(RT_ERR_INVALID, "rt_bvh_build_device: null argument");
+    rt_bvh_options opt { 0, 32, 64 };
+    if (options) opt = *options;
+    std::vector<int> order;
+    bool useOrder = false;
+    try {
+        if (device_sort_applies(scene->host, opt)) {
+            std::vector<float> centroids;
+            primitive_centroids(scene->host, centroids);
+            bool ambiguous = false;
+            RT_HIP(device_split_order(centroids.data(), centroids.size() / 3, order, ambiguous, nullptr));
+            useOrder = !ambiguous;
+        }
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_LIMIT, std::string("rt_bvh_build_device: ") + e.what());
+    }
+    if (!useOrder) return rt_bvh_build(scene, options, out);
+    *out = nullptr;
+    if (opt.max_level < 0 || opt.max_level > RT_MAX_LEVELS - 1) return fail(RT_ERR_LIMIT, "max_level must be in [0, 32]");
+    rt_bvh* b = new (std::nothrow) rt_bvh;
+    if (!b) return fail(RT_ERR_INVALID, "out of host memory");
+    b->scene = scene;
+    b->deviceSorted = true;
+    try {
+        build_bvh(scene->host, opt, b->host, &order);
+        flatten_bvh(scene->host, b->host, b->flat);
+    } catch (const std::exception& e) {
+        delete b;
+        return fail(RT_ERR_LIMIT, std::string("rt_bvh_build_device: ") + e.what());
+    } catch (...) {
+        delete b;
+        return fail(RT_ERR_LIMIT, "rt_bvh_build_device: unknown failure");
+    }
+    *out = b;
+    return RT_OK;
+}
+
+int32_t rt_bvh_device_sorted(const rt_bvh* b) { return b && b->deviceSorted ? 1 : 0; }
 
 void rt_bvh_destroy(rt_bvh* b)
 {
