@@ -93,6 +93,10 @@ struct rt_bvh {
     std::mutex lock;
     DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
+    // second stream (and its fork / join events) on which a direct-lighting pass finishes its long camera rays
+    hipStream_t auxStream = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    DevBuf gaveUpQueue, pairSpillAux;
 };
 
 namespace {
@@ -255,6 +259,9 @@ rt_status upload_bvh(rt_bvh* b)
     for (hipEvent_t& e : b->evSplit)
         if (!e) RT_HIP(hipEventCreate(&e));
     if (!b->evStop) RT_HIP(hipEventCreate(&b->evStop));
+    if (!b->auxStream) RT_HIP(hipStreamCreateWithFlags(&b->auxStream, hipStreamNonBlocking));
+    if (!b->evFork) RT_HIP(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
+    if (!b->evJoin) RT_HIP(hipEventCreateWithFlags(&b->evJoin, hipEventDisableTiming));
     SceneView& v = b->view;
     v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
     v.prims = static_cast<const PrimRec*>(b->prims.ptr);
@@ -497,13 +504,16 @@ int32_t rt_bvh_device_sorted(const rt_bvh* b) { return b && b->deviceSorted ? 1 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->wfRays, &b->wfNodes, &b->wfMeta, &b->wfValue, &b->wfHits, &b->wfHitNode, &b->wfGlossy })
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->wfRays, &b->wfNodes, &b->wfMeta, &b->wfValue, &b->gaveUpQueue, &b->pairSpillAux, &b->wfHits, &b->wfHitNode, &b->wfGlossy })
         d->release();
     if (b->evStart) (void)hipEventDestroy(b->evStart);
     if (b->evMid) (void)hipEventDestroy(b->evMid);
     for (hipEvent_t e : b->evSplit)
         if (e) (void)hipEventDestroy(e);
     if (b->evStop) (void)hipEventDestroy(b->evStop);
+    if (b->evFork) (void)hipEventDestroy(b->evFork);
+    if (b->evJoin) (void)hipEventDestroy(b->evJoin);
+    if (b->auxStream) (void)hipStreamDestroy(b->auxStream);
     delete b;
 }
 
@@ -639,6 +649,8 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
 
     FrameParams P;
     std::memset(&P, 0, sizeof P);
+    SplitAux aux {};
+    bool useAux = false;
     P.scene = b->view;
     fill_camera(*camera, P);
     P.width = width;
@@ -746,7 +758,8 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             if (cap < 2 * nodes) cap = 2 * nodes; // a chunk has at most `nodes` roots and `nodes` nodes, each with at most one hit entry
         }
         RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
-        RT_HIP(b->queueCounters.reserve(Q_COUNT * sizeof(unsigned long long)));
+        RT_HIP(b->queueCounters.reserve(3 * Q_COUNT * sizeof(unsigned long long)));
+        RT_HIP(b->gaveUpQueue.reserve(cap * sizeof(uint32_t)));
         const size_t items = cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1);
         if (items >= (size_t(1) << 32)) return fail(RT_ERR_LIMIT, "too many shadow samples per pass (pixels x samples x light samples must stay below 2^32)");
         RT_HIP(b->visibility.reserve(items));
@@ -758,7 +771,27 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             P.pairSpill = static_cast<uint32_t*>(b->pairSpill.ptr);
         }
         P.queue = static_cast<HitEntry*>(b->queue.ptr);
-        P.queueCounters = static_cast<unsigned long long*>(b->queueCounters.ptr);
+        // counter blocks: primary pass, lighting round A, lighting round B (one block serves all when the rounds are not split)
+        static const int overlap = [] {
+            const char* e = std::getenv("RT_OVERLAP"); // 0: the camera rays that gave up are finished before any lighting starts
+            return e ? std::atoi(e) : 1;
+        }();
+        P.primaryCounters = static_cast<unsigned long long*>(b->queueCounters.ptr);
+        P.queueCounters = P.primaryCounters + (overlap ? Q_COUNT : 0);
+        P.gaveUpQueue = static_cast<uint32_t*>(b->gaveUpQueue.ptr);
+        P.shadowQueueItems = uint32_t(items);
+        if (overlap) {
+            aux.stream = b->auxStream;
+            aux.fork = b->evFork;
+            aux.join = b->evJoin;
+            aux.counters = P.primaryCounters + 2 * Q_COUNT;
+            aux.pairSpillWaves = 2048; // the second round is small
+            if (P.pairSpillEntries > 0) {
+                RT_HIP(b->pairSpillAux.reserve(size_t(aux.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
+                aux.pairSpill = static_cast<uint32_t*>(b->pairSpillAux.ptr);
+            }
+            useAux = true;
+        }
         P.visibility = static_cast<uint8_t*>(b->visibility.ptr);
         P.queueCapacity = cap;
     }
@@ -776,7 +809,7 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     if (stats) RT_HIP(hipEventRecord(b->evStart, s));
     bool splitRecorded = false;
     unsigned long long wavefrontNodes = 0;
-    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr, stats ? b->evSplit : nullptr, &splitRecorded, &wavefrontNodes));
+    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr, stats ? b->evSplit : nullptr, &splitRecorded, &wavefrontNodes, useAux ? &aux : nullptr));
     if (stats) RT_HIP(hipEventRecord(b->evStop, s));
     if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
     if (wait) RT_HIP(hipStreamSynchronize(s));

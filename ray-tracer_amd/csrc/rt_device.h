@@ -95,7 +95,12 @@ struct FrameParams {
     int32_t countTests;
     // queue passes (direct-lighting frames): the hits of the camera rays, one entry each
     struct HitEntry* queue;
-    unsigned long long* queueCounters; // Q_COUNT counters of the current pass, see below
+    unsigned long long* queueCounters; // Q_COUNT counters of the current pass, see below: those of the lighting passes
+    unsigned long long* primaryCounters; // ... and those of the primary pass (hit-queue length, rays that gave up, cursors);
+                                       // the same block unless two lighting rounds of a pass run side by side
+    uint32_t* gaveUpQueue;             // camera rays (sample * pixels + pixel) that gave up in k_primary
+    int32_t shadowQueueReversed;       // shadow work items are stored from the END of shadowQueue downwards (the second
+    uint32_t shadowQueueItems;         // lighting round shares the buffer with the first); its capacity in items
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
                                        // primary pass: the camera rays (sample * pixels + pixel) that gave up
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
@@ -138,7 +143,9 @@ enum {
     Q_WF_NODES = 80 + 16 * 16,     // wavefront: nodes allocated so far in the chunk
     Q_WF_GLOSSY = Q_WF_NODES + 16, // glossy calls of the current generation
     Q_WF_OVERFLOW = Q_WF_GLOSSY + 16, // set when a generation did not fit the node or glossy capacity
-    Q_COUNT = Q_WF_OVERFLOW + 16
+    Q_RANGE_BEGIN = Q_WF_OVERFLOW + 16, // lighting passes (cull / shadow / shade): the hit-queue entries they work on,
+    Q_RANGE_END = Q_RANGE_BEGIN + 16,   // set by k_range once the entries exist
+    Q_COUNT = Q_RANGE_END + 16
 };
 
 struct Counts {

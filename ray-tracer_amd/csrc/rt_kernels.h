@@ -14,8 +14,18 @@ enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TR
 // in a single chunk; *splitRecorded says whether that happened.
 // *wavefrontNodes (when not null) receives the number of call-tree nodes the wavefront passes evaluated (0 when the
 // call did not run as wavefront passes).
+// `aux` (when not null): what a direct-lighting pass needs to finish the camera rays that gave up, and light their
+// hits, on a second stream beside the lighting of the other hits: that stream, two events, a counter block (the third
+// of the three blocks that start at P.primaryCounters; the second is P.queueCounters) and spill space for its shadow pass.
+struct SplitAux {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+    unsigned long long* counters;
+    uint32_t* pairSpill;
+    uint32_t pairSpillWaves;
+};
 hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded,
-    unsigned long long* wavefrontNodes = nullptr);
+    unsigned long long* wavefrontNodes = nullptr, const SplitAux* aux = nullptr);
 
 // Shadow pass sizing: clamps P.pairStackLds to what the hierarchy can need and sets P.pairSpillEntries (per wave)
 // and P.pairSpillWaves (the most waves the pass is launched with); the caller provides P.pairSpill accordingly.

@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
             bool gotChunk = false;
             while (cursorsTried < PRIMARY_CURSORS) {
                 uint32_t i = 0;
-                if (lane == 0) i = uint32_t(atomicAdd(&P.queueCounters[Q_PRIMARY_CURSORS + cursor * 16u], 1ull));
+                if (lane == 0) i = uint32_t(atomicAdd(&P.primaryCounters[Q_PRIMARY_CURSORS + cursor * 16u], 1ull));
                 i = __builtin_amdgcn_readfirstlane(i);
                 chunk = cursor * perCursor + i;
                 if (i < perCursor && chunk < nChunks) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
         if (hits) {
             const int leader = __ffsll((long long)hits) - 1;
             unsigned int base = 0;
-            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(hits));
+            if (lane == leader) base = (unsigned int)atomicAdd(&P.primaryCounters[Q_HITS], (unsigned long long)__popcll(hits));
             base = __shfl(base, leader, 64);
             if (slot >= 0) {
                 HitEntry e;
@@ -222,9 +222,9 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
         if (gaveUp) {
             const int leader = __ffsll((long long)gaveUp) - 1;
             unsigned int base = 0;
-            if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_GAVE_UP], (unsigned long long)__popcll(gaveUp));
+            if (lane == leader) base = (unsigned int)atomicAdd(&P.primaryCounters[Q_GAVE_UP], (unsigned long long)__popcll(gaveUp));
             base = __shfl(base, leader, 64);
-            if (slot == TRAVERSE_GAVE_UP) P.shadowQueue[base + lanes_below(gaveUp)] = work;
+            if (slot == TRAVERSE_GAVE_UP) P.gaveUpQueue[base + lanes_below(gaveUp)] = work;
         }
     }
     flush_counts(cnt, P.stats);
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
     extern __shared__ uint2 lds_stack[];
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
     Counts cnt;
-    const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
+    const unsigned int nHits = (unsigned int)P.primaryCounters[Q_HITS];
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     for (unsigned int q = blockIdx.x * WAVE + threadIdx.x; q < nHits; q += gridDim.x * WAVE) {
         HitEntry e = P.queue[q];
@@ -266,6 +266,14 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
     flush_counts(cnt, P.stats);
 }
 
+// Hands a lighting round (cull / shadow / shade) its part of the hit queue: from where `beginFrom` says (null: the
+// start) to the queue's current length.
+__global__ void k_range(unsigned long long* round, const unsigned long long* beginFrom, const unsigned long long* length)
+{
+    round[Q_RANGE_BEGIN] = beginFrom ? *beginFrom : 0ull;
+    round[Q_RANGE_END] = *length;
+}
+
 // Cull pass: one lane per queued hit.  Decides, for every shadow-casting light sample of the hit, whether the
 // visibility bit can reach the pixel at all.  With shading on, the reference multiplies the bit with a Phong
 // term (src/light.cpp:141-143,175-178,209-212) that is exactly zero when dot(N, L) <= 0 (src/shading.cpp:14-38):
@@ -275,16 +283,16 @@ __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
 // of a hit next to each other and hits in queue order (one atomic per wave).
 __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 {
-    const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
+    const unsigned int qBegin = (unsigned int)P.queueCounters[Q_RANGE_BEGIN], nHits = (unsigned int)P.queueCounters[Q_RANGE_END];
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const int lane = int(threadIdx.x) & 63;
-    const unsigned int rounded = (nHits + 63u) & ~63u; // whole waves stay in the loop together
+    const unsigned int rounded = qBegin + ((nHits - qBegin + 63u) & ~63u); // whole waves stay in the loop together
     uint32_t culled = 0;
     bool everyLightShadowed = true;
     for (int li = 0; li < P.nLights; li++)
         if (light_enabled(P, P.lights[li].type) && P.lights[li].shadowBase < 0) everyLightShadowed = false;
-    for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < rounded; q += gridDim.x * BLOCK) {
+    for (unsigned int q = qBegin + blockIdx.x * BLOCK + threadIdx.x; q < rounded; q += gridDim.x * BLOCK) {
         bool live = q < nHits;
         Rng rng;
         RayD r = make_ray(splat3(0.0f), splat3(1.0f));
@@ -344,7 +352,8 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                             if (wanted && j < 64) wantedBits |= 1ull << j;
                             if (!wanted) culled++; // its visibility byte is never written: k_shade multiplies it with exact zeros
                         } else if (wanted) {
-                            P.shadowQueue[at++] = item;
+                            P.shadowQueue[P.shadowQueueReversed ? P.shadowQueueItems - 1u - at : at] = item;
+                            at++;
                         }
                     }
                 }
@@ -527,7 +536,8 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
     Counts cnt;
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
-    const unsigned long long queued = P.queueCounters[PRIMARY ? Q_GAVE_UP : Q_SHADOW_ITEMS];
+    unsigned long long* const counters = PRIMARY ? P.primaryCounters : P.queueCounters;
+    const unsigned long long queued = counters[PRIMARY ? Q_GAVE_UP : Q_SHADOW_ITEMS];
     // camera rays that gave up are long by construction: a quarter of the slots at most gives the stream enough pairs
     // and spreads the (often few) rays over more waves ...
     uint32_t raysPerPacket = STREAM_RAYS;
@@ -546,7 +556,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
     // Packets of 64 consecutive queued queries come from a cursor.
     while (true) {
         unsigned long long pk = 0;
-        if (lane == 0) pk = atomicAdd(&P.queueCounters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
+        if (lane == 0) pk = atomicAdd(&counters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
         pk = __shfl(pk, 0, 64);
         if (pk >= nPackets) break;
         // ---- this lane's query; the ones that pass the root gate start as pairs (ray, root)
@@ -558,7 +568,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
         if (have) {
             if (PRIMARY) {
                 // a camera ray that gave up in k_primary
-                work = P.shadowQueue[qi];
+                work = P.gaveUpQueue[qi];
                 HitEntry e;
                 e.work = work;
                 Rng rng;
@@ -566,7 +576,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 int sidx;
                 hit_ray(P, 0u, e, nPix, rng, r, pix, sidx); // (a camera ray: never a wavefront node)
             } else {
-                work = P.shadowQueue[qi];
+                work = P.shadowQueue[P.shadowQueueReversed ? (unsigned long long)P.shadowQueueItems - 1ull - qi : qi];
                 const HitEntry e = P.queue[work / perHit];
                 const int j = int(work % perHit);
                 Rng rng;
@@ -771,7 +781,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
             if (hits) {
                 const int leader = __ffsll((long long)hits) - 1;
                 unsigned int base = 0;
-                if (lane == leader) base = (unsigned int)atomicAdd(&P.queueCounters[Q_HITS], (unsigned long long)__popcll(hits));
+                if (lane == leader) base = (unsigned int)atomicAdd(&P.primaryCounters[Q_HITS], (unsigned long long)__popcll(hits));
                 base = __shfl(base, leader, 64);
                 if (have && found) {
                     HitEntry e;
@@ -792,9 +802,9 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
 // (reference src/light.cpp:124-220 for a hit whose colour is Lo, src/render.cpp:64-67).
 __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
 {
-    const unsigned int nHits = (unsigned int)P.queueCounters[Q_HITS];
+    const unsigned int qBegin = (unsigned int)P.queueCounters[Q_RANGE_BEGIN], nHits = (unsigned int)P.queueCounters[Q_RANGE_END];
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
-    for (unsigned int q = blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
+    for (unsigned int q = qBegin + blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
         const HitEntry e = P.queue[q];
         if (e.slot < 0 || e.pad != 0) continue; // nothing found after all / colour already written by k_cull
         Rng rng;
@@ -1415,43 +1425,80 @@ void launch_stream(const FrameParams& P, uint32_t wanted, size_t lds, hipStream_
     }
 }
 
+// The queue passes of one sample range.  The hits of a pass come in two lots: those k_primary queues itself (nearly
+// all) and those of the camera rays that gave up, which k_stream (primary mode) and k_closest finish — two kernels
+// that run a handful of long rays each and leave the chip almost empty for most of a millisecond.  With `aux` (a
+// second stream of the library's own, a second set of counters and spill space) the second lot gets a lighting round
+// of its own, and that round together with the two kernels runs on the second stream beside the first lot's
+// lighting: round A = entries [0, a) of the hit queue, shadow items stored from the front of their queue; round
+// B = entries [a, end), items stored from the back; the visibility bytes are indexed by hit and never overlap.
 template <bool PRUNE>
-hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev)
+hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hipStream_t stream, hipEvent_t* ev, const SplitAux* aux)
 {
     const size_t streamLds = stream_lds_bytes(P.pairStackLds);
     {
-        {
-            // enough chunks for every resident wave to come back to the cursor several times
-            const uint32_t waves = P.countTests ? resident_blocks(k_primary<PRUNE, true>, WAVE, lds) : resident_blocks(k_primary<PRUNE, false>, WAVE, lds);
-            uint32_t chunk = P.logicalBlocks / (waves * 8u);
-            chunk = chunk < 1u ? 1u : (chunk > PRIMARY_CHUNK_MAX ? PRIMARY_CHUNK_MAX : chunk);
-            FrameParams Q = P;
-            Q.primaryChunk = chunk;
-            // A small pass (a rank's share of a frame on several GPUs) ends when its slowest tile does, and the slowest
-            // tiles are the ones whose rays use up the whole budget: with few tiles per wave a smaller budget shortens
-            // the pass (measured: 1/8 of the headline frame 1.18 -> 1.00 ms), with many it only moves work to the
-            // kernels behind (whole frame 2.69 -> 3.59 ms).
-            if (P.logicalBlocks < waves * uint32_t(P.primarySmallPass) && Q.primaryBudget > 32) Q.primaryBudget = 32;
-            if (Q.countTests) launch_walkers(k_primary<PRUNE, true>, Q, lds, stream);
-            else launch_walkers(k_primary<PRUNE, false>, Q, lds, stream);
-        }
+        // enough chunks for every resident wave to come back to the cursor several times
+        const uint32_t waves = P.countTests ? resident_blocks(k_primary<PRUNE, true>, WAVE, lds) : resident_blocks(k_primary<PRUNE, false>, WAVE, lds);
+        uint32_t chunk = P.logicalBlocks / (waves * 8u);
+        chunk = chunk < 1u ? 1u : (chunk > PRIMARY_CHUNK_MAX ? PRIMARY_CHUNK_MAX : chunk);
+        FrameParams Q = P;
+        Q.primaryChunk = chunk;
+        // A small pass (a rank's share of a frame on several GPUs) ends when its slowest tile does, and the slowest
+        // tiles are the ones whose rays use up the whole budget: with few tiles per wave a smaller budget shortens
+        // the pass (measured: 1/8 of the headline frame 1.18 -> 1.00 ms), with many it only moves work to the
+        // kernels behind (whole frame 2.69 -> 3.59 ms).
+        if (P.logicalBlocks < waves * uint32_t(P.primarySmallPass) && Q.primaryBudget > 32) Q.primaryBudget = 32;
+        if (Q.countTests) launch_walkers(k_primary<PRUNE, true>, Q, lds, stream);
+        else launch_walkers(k_primary<PRUNE, false>, Q, lds, stream);
+    }
+    auto finish_gave_up = [&](hipStream_t st) {
         // how many rays gave up, and how many of those meet a primitive, is only known on the device: both kernels
-        // get a grid that covers every resident wave
-        launch_stream<true>(P, gridDirect.x, streamLds, stream);
+        // get a grid that covers every resident wave (on the second stream the stream kernel spills to that stream's
+        // space: the first round's shadow pass may be running)
+        FrameParams G = P;
+        if (aux) {
+            G.pairSpill = aux->pairSpill;
+            G.pairSpillWaves = aux->pairSpillWaves;
+        }
+        launch_stream<true>(G, gridDirect.x, streamLds, st);
         const uint32_t walkers = P.countTests ? resident_blocks(k_closest<PRUNE, true>, WAVE, lds) : resident_blocks(k_closest<PRUNE, false>, WAVE, lds);
         const dim3 gc(gridDirect.x < walkers ? gridDirect.x : walkers);
-        if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, stream, P);
-        else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), lds, stream, P);
+        if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, st, P);
+        else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), lds, st, P);
+    };
+    auto lighting = [&](const FrameParams& R, hipStream_t st, hipEvent_t* marks) {
+        if (R.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, st, R);
+        if (marks) (void)hipEventRecord(marks[1], st);
+        if (R.shadowSamplesPerHit > 0) launch_stream<false>(R, gridDirect.x, streamLds, st);
+        if (marks) (void)hipEventRecord(marks[2], st);
+        hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, st, R);
+        if (marks) (void)hipEventRecord(marks[3], st);
+    };
+    if (!aux) {
+        finish_gave_up(stream);
+        hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, stream, P.queueCounters, (const unsigned long long*)nullptr, (const unsigned long long*)&P.primaryCounters[Q_HITS]);
+        if (ev) (void)hipEventRecord(ev[0], stream);
+        lighting(P, stream, ev);
+        return hipGetLastError();
     }
+    hipError_t e;
+    // round A: what k_primary queued
+    hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, stream, P.queueCounters, (const unsigned long long*)nullptr, (const unsigned long long*)&P.primaryCounters[Q_HITS]);
     if (ev) (void)hipEventRecord(ev[0], stream);
-    if (P.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
-    if (ev) (void)hipEventRecord(ev[1], stream);
-    if (P.shadowSamplesPerHit > 0) {
-        launch_stream<false>(P, gridDirect.x, streamLds, stream);
-    }
-    if (ev) (void)hipEventRecord(ev[2], stream);
-    hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
-    if (ev) (void)hipEventRecord(ev[3], stream);
+    if ((e = hipEventRecord(aux->fork, stream)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(aux->stream, aux->fork, 0)) != hipSuccess) return e;
+    // second stream: the rays that gave up, then round B
+    finish_gave_up(aux->stream);
+    FrameParams B = P;
+    B.queueCounters = aux->counters;
+    B.shadowQueueReversed = 1;
+    B.pairSpill = aux->pairSpill;
+    B.pairSpillWaves = aux->pairSpillWaves;
+    hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, aux->stream, B.queueCounters, (const unsigned long long*)&P.queueCounters[Q_RANGE_END], (const unsigned long long*)&P.primaryCounters[Q_HITS]);
+    lighting(B, aux->stream, nullptr);
+    if ((e = hipEventRecord(aux->join, aux->stream)) != hipSuccess) return e;
+    lighting(P, stream, ev);
+    if ((e = hipStreamWaitEvent(stream, aux->join, 0)) != hipSuccess) return e;
     return hipGetLastError();
 }
 
@@ -1544,6 +1591,7 @@ hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipS
             }
         }
         // direct lighting of every call that needs it, all generations at once
+        hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, stream, P.queueCounters, (const unsigned long long*)nullptr, (const unsigned long long*)&P.queueCounters[Q_HITS]);
         P.wfLighting = 1;
         if (P.shadowSamplesPerHit > 0) {
             hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
@@ -1594,7 +1642,7 @@ bool direct_only(const FrameParams& P)
 }
 
 hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* splitEvents, bool* splitRecorded,
-    unsigned long long* wavefrontNodes)
+    unsigned long long* wavefrontNodes, const SplitAux* aux)
 {
     if (splitRecorded) *splitRecorded = false;
     unsigned long long nodesEvaluated = 0;
@@ -1624,12 +1672,13 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
         P.sampleEnd = sEnd;
         P.logicalBlocks = tiles * uint32_t(sEnd - sBegin);
         if (split) {
-            if ((e = hipMemsetAsync(P.queueCounters, 0, Q_COUNT * sizeof(unsigned long long), stream)) != hipSuccess) return e;
+            // the counter blocks of the pass (primary pass, lighting round A, lighting round B) are one allocation
+            if ((e = hipMemsetAsync(P.primaryCounters, 0, (aux ? 3 : 1) * Q_COUNT * sizeof(unsigned long long), stream)) != hipSuccess) return e;
             const uint32_t waves = uint32_t((size_t(rows) * size_t(P.width) * size_t(sEnd - sBegin) + WAVE - 1) / WAVE);
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
             if (ev && splitRecorded) *splitRecorded = true;
-            return prune ? launch_split_t<true>(P, gridDirect, lds, stream, ev) : launch_split_t<false>(P, gridDirect, lds, stream, ev);
+            return prune ? launch_split_t<true>(P, gridDirect, lds, stream, ev, aux) : launch_split_t<false>(P, gridDirect, lds, stream, ev, aux);
         }
         if (prune) return glossy ? launch_render_t<true, true>(P, lds, stream) : launch_render_t<true, false>(P, lds, stream);
         return glossy ? launch_render_t<false, true>(P, lds, stream) : launch_render_t<false, false>(P, lds, stream);
