@@ -1492,6 +1492,7 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
     FrameParams B = P;
     B.queueCounters = aux->counters;
     B.shadowQueueReversed = 1;
+    B.streamGroup = 1; // the second round's few queries belong to scattered hits: nothing to share an entry
     B.pairSpill = aux->pairSpill;
     B.pairSpillWaves = aux->pairSpillWaves;
     hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, aux->stream, B.queueCounters, (const unsigned long long*)&P.queueCounters[Q_RANGE_END], (const unsigned long long*)&P.primaryCounters[Q_HITS]);
