@@ -513,7 +513,10 @@ void rt_bvh_destroy(rt_bvh* b)
     if (b->evStop) (void)hipEventDestroy(b->evStop);
     if (b->evFork) (void)hipEventDestroy(b->evFork);
     if (b->evJoin) (void)hipEventDestroy(b->evJoin);
-    if (b->auxStream) (void)hipStreamDestroy(b->auxStream);
+    if (b->auxStream) {
+        (void)hipStreamSynchronize(b->auxStream); // (joined into the caller's stream at the end of every pass; nothing should be left)
+        (void)hipStreamDestroy(b->auxStream);
+    }
     delete b;
 }
 
