@@ -222,7 +222,13 @@ rt_status rt_visibility_batch(const rt_bvh* bvh, const rt_ray* rays_with_hit_t, 
  * width x height frame (the reference's y).  `out_rgb` receives (row_end-row_begin)*width float RGB pixels,
  * top-most of those rows first — i.e. the slice of the Screen buffer those rows occupy; host pointer when
  * device_ptr == 0, device pointer otherwise.  Bloom, which needs the whole frame, is NOT applied here even
- * if features->bloom is set: call rt_bloom on the assembled frame. */
+ * if features->bloom is set: call rt_bloom on the assembled frame.
+ * Calls on one rt_bvh are serialised by the library (several threads may render from one hierarchy, as the reference's
+ * per-camera threads do, src/main.cpp:533-552).  With a host frame or a stats pointer the call returns when the frame
+ * is complete.  With a device frame and stats == NULL it only queues the work on `stream` and returns: the per-call
+ * scratch of the rt_bvh is then still in use, so the next call on that rt_bvh must be queued on the same stream or come
+ * after the caller has waited for it.  The library may run part of a call on a stream of its own; that stream is
+ * joined into `stream` before the call's work on `stream` ends. */
 rt_status rt_render(const rt_bvh* bvh, const rt_camera* camera, const rt_light* lights, int32_t n_lights,
     const rt_features* features, const rt_params* params, int32_t width, int32_t height, int32_t row_begin,
     int32_t row_end, float* out_rgb, int32_t device_ptr, void* stream, rt_stats* stats);
