@@ -1,0 +1,84 @@
+"""Randomly drawn feature / parameter combinations (fixed seeds), GPU against the oracle at small sizes: the combinations
+no hand-written case names — e.g. see-through + mirror + soft shadows + depth of field through the wavefront passes, or
+supersampling + sky box + glossy in the per-lane kernel."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import golden_cases as gc
+import oracle_lib as o
+
+rt = o.rt
+pytestmark = pytest.mark.gpu
+
+SCENES = ["cornell_para", "transparent_cubes", "transparent_cornell", "monkey", "cube_textured", "cube_segment", "bumpy"]
+_state = {}
+
+
+def _scene(lib, name):
+    if name not in _state:
+        if name == "bumpy":
+            synth = importlib.import_module("ray-tracer_amd.synth")
+            sc = rt.SceneData([synth.dragon_class_mesh(2)], lights=synth.area_light())
+        else:
+            sc = rt.SceneData.from_golden(o.golden(name))
+        _state[name] = (sc, o.OracleScene(sc), lib.bvh_build(lib.scene_create(sc)))
+    return _state[name]
+
+
+def _draw(rng):
+    f = dict(shading=int(rng.random() < 0.8), recursive=int(rng.random() < 0.35), hard_shadow=int(rng.random() < 0.5),
+             soft_shadow=int(rng.random() < 0.5), normal_interp=int(rng.random() < 0.4), texture_mapping=int(rng.random() < 0.5),
+             bilinear_filtering=int(rng.random() < 0.3), environment_mapping=int(rng.random() < 0.3), glossy=int(rng.random() < 0.35),
+             transparency=int(rng.random() < 0.4), multiple_rays=int(rng.random() < 0.4), depth_of_field=int(rng.random() < 0.3))
+    p = dict(ray_multiplier=int(rng.integers(1, 4)), ray_depth=int(rng.integers(0, 4)), glossy_filter_size=int(rng.integers(1, 6)),
+             glossy_sigma=float(rng.choice([0.5, 1.0, 3.0])), dof_samples=int(rng.integers(0, 5)), dof_f=float(rng.choice([2.2, 2.5, 3.0])),
+             dof=float(rng.choice([0.0, 0.05, 0.3])), enabled_skybox=int(rng.random() < 0.6), enabled_refl_map=int(rng.random() < 0.15),
+             samples_per_unit=int(rng.integers(1, 12)), samples_per_unit_parallel=int(rng.integers(3, 12)), seed=int(rng.integers(1, 1000)))
+    return f, p
+
+
+@pytest.mark.parametrize("seed", range(150))
+def test_random_feature_combination_matches_oracle(seed):
+    lib = rt.Library()
+    lib.init(0)
+    rng = np.random.default_rng(1000 + seed)
+    name = SCENES[int(rng.integers(0, len(SCENES)))]
+    sc, orc, bvh = _scene(lib, name)
+    f, p = _draw(rng)
+    if sc.skybox is None:
+        f["environment_mapping"] = 0  # (the library refuses a sky box lookup in a scene that has none)
+    feats, params = rt.features(**f), rt.default_params(**p)
+    W, H = int(rng.integers(17, 57)), int(rng.integers(9, 41))
+    which = "A" if rng.random() < 0.6 else "B"
+    cam = rt.make_camera(width=W, height=H, **(o.CAM_A if which == "A" else o.CAM_B))
+    lights, n = sc.light_array()
+    img, stats = lib.render(bvh, cam, lights, n, feats, params, W, H)
+    ref, ostats = orc.render(cam, feats, params, W, H)
+    assert np.isfinite(img).all() == np.isfinite(ref).all()
+    ok = np.isfinite(ref)
+    err = np.abs(np.where(ok, img, 0) - np.where(ok, ref, 0)).max(axis=2)
+    what = f"{name} {W}x{H} cam {which} {f} {p}"
+    if f["glossy"]:
+        assert (err > 1e-4).mean() <= 0.02, f"{what}: {(err > 1e-4).sum()} pixels differ, max {err.max()}"
+    else:
+        assert err.max() <= 4e-6, f"{what}: max abs diff {err.max()} on {(err > 4e-6).sum()} pixels"
+    assert stats.primary_rays == ostats.primary_rays, what
+    assert stats.bounce_rays == ostats.bounce_rays, what
+    assert stats.transparency_overflows == ostats.transparency_overflows, what
+
+
+@pytest.mark.skipif(os.environ.get("RT_TEST_CHILD") == "1", reason="already the child run")
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_random_cases_in_both_evaluation_orders(mode):
+    """The same draws with every bounce frame forced through the per-lane kernel (RT_WAVEFRONT=0) or through the
+    wavefront passes (RT_WAVEFRONT=1), in a child process (the knob is read once per process)."""
+    env = dict(os.environ, RT_TEST_CHILD="1", RT_WAVEFRONT=mode)
+    cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k", "random_feature_combination"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert " passed" in out.stdout
