@@ -42,7 +42,7 @@ def _draw(rng):
     return f, p
 
 
-@pytest.mark.parametrize("seed", range(150))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RT_RANDOM_CASES", "150"))))
 def test_random_feature_combination_matches_oracle(seed):
     lib = rt.Library()
     lib.init(0)
