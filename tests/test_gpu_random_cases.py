@@ -82,3 +82,65 @@ def test_random_cases_in_both_evaluation_orders(mode):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert " passed" in out.stdout
+
+
+def _random_rays(rng, sc, n):
+    """Rays that stress the slab and triangle tests: arbitrary ones, axis-parallel ones, directions with components at and
+    around the 1e-6 "zero" threshold, rays aimed at vertices and edge midpoints, origins inside the scene, finite bounds."""
+    verts = np.concatenate([m["vertices"][:, :3] for m in sc.meshes]) if sc.meshes else np.zeros((1, 3), np.float32)
+    o3 = (rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(5.0)
+    inside = rng.random(n) < 0.3
+    o3[inside] = verts[rng.integers(0, len(verts), inside.sum())] * np.float32(0.5)
+    d3 = (rng.random((n, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(2.0)
+    aimed = rng.random(n) < 0.4
+    target = verts[rng.integers(0, len(verts), n)]
+    mid = (target + verts[rng.integers(0, len(verts), n)]) * np.float32(0.5)
+    target = np.where((rng.random(n) < 0.5)[:, None], target, mid)
+    d3[aimed] = (target - o3)[aimed]
+    for axis in range(3):
+        kind = rng.random(n)
+        d3[kind < 0.08, axis] = 0.0
+        d3[(kind >= 0.08) & (kind < 0.12), axis] = np.float32(1e-6)
+        d3[(kind >= 0.12) & (kind < 0.16), axis] = np.float32(-1.0000001e-6)
+        d3[(kind >= 0.16) & (kind < 0.19), axis] = np.float32(2e-6)
+    dead = ~np.any(d3 != 0, axis=1)
+    d3[dead] = np.float32([0.0, 0.0, 1.0])
+    norm = rng.random(n) < 0.5
+    d3[norm] = d3[norm] / np.linalg.norm(d3[norm], axis=1, keepdims=True).astype(np.float32)
+    rays = np.zeros(n, rt.RAY_DTYPE)
+    rays["origin"], rays["direction"] = o3, d3
+    rays["t"] = np.where(rng.random(n) < 0.7, np.float32(3.4028234663852886e38), (rng.random(n) * 3).astype(np.float32))
+    return rays
+
+
+@pytest.mark.parametrize("scene", ["cornell", "monkey", "transparent_cubes", "cube_textured", "single_triangle", "spheres", "bumpy"])
+def test_random_rays_hit_records_bit_exact(scene):
+    lib = rt.Library()
+    lib.init(0)
+    sc, orc, bvh = _scene(lib, scene)
+    rng = np.random.default_rng(77)
+    rays = _random_rays(rng, sc, 6000)
+    modes = [rt.features(normal_interp=1, texture_mapping=1), rt.features(recursive=1, texture_mapping=1, bilinear_filtering=1),
+             rt.features(transparency=1)]
+    if sc.n_triangles <= 2000:
+        modes.append(rt.features(normal_interp=1, accel_structure=0))
+    for feats in modes:
+        h, ho = lib.intersect(bvh, rays, feats), orc.intersect(rays, feats)
+        assert np.array_equal(h["hit"], ho["hit"])
+        assert np.array_equal(h["t"].view(np.uint32), ho["t"].view(np.uint32))
+        m = h["hit"] == 1
+        for k in ("mesh", "triangle"):
+            assert np.array_equal(h[k][m], ho[k][m]), k
+        for k in ("normal", "bary", "kd"):
+            a, b = h[k][m], ho[k][m]
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), f"{k}: {(~same).any(axis=1).sum()} hits differ"
+    # shadow queries from the hit points towards random positions
+    feats = rt.features(shading=1, hard_shadow=1, soft_shadow=1)
+    h = lib.intersect(bvh, rays, feats)
+    m = h["hit"] == 1
+    if m.any():
+        hit_rays = rays[m].copy()
+        hit_rays["t"] = h["t"][m]
+        samples = (rng.random((12, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(4.0)
+        assert np.array_equal(lib.visibility(bvh, hit_rays, samples, feats), orc.visibility(hit_rays, samples, feats))
