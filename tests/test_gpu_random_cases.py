@@ -144,3 +144,35 @@ def test_random_rays_hit_records_bit_exact(scene):
         hit_rays["t"] = h["t"][m]
         samples = (rng.random((12, 3), dtype=np.float32) - np.float32(0.5)) * np.float32(4.0)
         assert np.array_equal(lib.visibility(bvh, hit_rays, samples, feats), orc.visibility(hit_rays, samples, feats))
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_row_block_shares_compose_to_the_whole_frame(seed):
+    """rt_render_blocks with a random block height, rank count and feature set: the shares put together equal the frame
+    rendered in one call, bit for bit (random streams are keyed by absolute pixel; the passes see other tile shapes)."""
+    lib = rt.Library()
+    lib.init(0)
+    rng = np.random.default_rng(5000 + seed)
+    name = SCENES[int(rng.integers(0, len(SCENES)))]
+    sc, orc, bvh = _scene(lib, name)
+    f, p = _draw(rng)
+    if sc.skybox is None:
+        f["environment_mapping"] = 0
+    feats, params = rt.features(**f), rt.default_params(**p)
+    W, H = int(rng.integers(9, 90)), int(rng.integers(5, 70))
+    cam = rt.make_camera(width=W, height=H, **o.CAM_A)
+    lights, n = sc.light_array()
+    full, _ = lib.render(bvh, cam, lights, n, feats, params, W, H)
+    world, block = int(rng.integers(1, 8)), int(rng.integers(1, 41))
+    frame = np.full_like(full, np.float32(-1.0))
+    n_blocks = (H + block - 1) // block
+    for r in range(world):
+        part, _ = lib.render_blocks(bvh, cam, lights, n, feats, params, W, H, block, r, world)
+        at = 0
+        for b in range(r, n_blocks, world):
+            top, bottom = b * block, min(H, (b + 1) * block)
+            frame[top:bottom] = part[at:at + bottom - top]
+            at += bottom - top
+        assert at == part.shape[0]
+    same = (frame.view(np.uint32) == full.view(np.uint32)) | (np.isnan(frame) & np.isnan(full))
+    assert same.all(), f"{name} {W}x{H} world {world} block {block} {f} {p}"
