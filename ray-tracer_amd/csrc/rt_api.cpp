@@ -279,6 +279,9 @@ rt_status upload_bvh(rt_bvh* b)
     v.hasSkybox = scene->host.skybox.size() == 6;
     v.hasSpheres = !scene->host.spheres.empty();
     v.stackDepth = b->host.numLevels;
+    v.bounded = 1;
+    for (int i = 0; i < 3; i++)
+        if (!(std::fabs(v.rootLo[i]) <= 1e30f && std::fabs(v.rootHi[i]) <= 1e30f)) v.bounded = 0;
     b->flat = FlatBvh {};
     b->uploaded = true;
     return RT_OK;

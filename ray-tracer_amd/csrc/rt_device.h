@@ -158,7 +158,11 @@ struct RayD {
     // src/intersect.cpp:114-126); functions of the ray only, so computed once per ray
     vec3 inv;
     bool zx, zy, zz;
+    // FAST CLASS of the slab test: no direction component in the zero class or non-finite, every origin component
+    // within +-FAST_BOUND (see box_pair_fast)
+    bool fast;
 };
+constexpr float FAST_BOUND = 1e30f;
 
 __device__ __forceinline__ RayD make_ray(vec3 o, vec3 d)
 {
@@ -167,16 +171,21 @@ __device__ __forceinline__ RayD make_ray(vec3 o, vec3 d)
     r.d = d;
     r.inv = make3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.zx = is_zero(d.x); r.zy = is_zero(d.y); r.zz = is_zero(d.z);
+    r.fast = !(r.zx || r.zy || r.zz) && fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX
+        && fabsf(o.x) <= FAST_BOUND && fabsf(o.y) <= FAST_BOUND && fabsf(o.z) <= FAST_BOUND;
     return r;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // One 64-byte record as four 16-byte loads.
 struct Rec64 {
-    float4 a, b, c, d;
+    f32x4 a, b, c, d;
 };
 __device__ __forceinline__ Rec64 load_rec(const void* p)
 {
-    const float4* q = static_cast<const float4*>(p);
+    const f32x4* q = static_cast<const f32x4*>(p);
     Rec64 r;
     r.a = q[0];
     r.b = q[1];
@@ -194,10 +203,10 @@ __device__ __forceinline__ Rec64 load_rec_uniform(const void* p)
     u32x16 v;
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     Rec64 r;
-    r.a = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-    r.b = make_float4(__uint_as_float(v[4]), __uint_as_float(v[5]), __uint_as_float(v[6]), __uint_as_float(v[7]));
-    r.c = make_float4(__uint_as_float(v[8]), __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]));
-    r.d = make_float4(__uint_as_float(v[12]), __uint_as_float(v[13]), __uint_as_float(v[14]), __uint_as_float(v[15]));
+    r.a = f32x4 { __uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]) };
+    r.b = f32x4 { __uint_as_float(v[4]), __uint_as_float(v[5]), __uint_as_float(v[6]), __uint_as_float(v[7]) };
+    r.c = f32x4 { __uint_as_float(v[8]), __uint_as_float(v[9]), __uint_as_float(v[10]), __uint_as_float(v[11]) };
+    r.d = f32x4 { __uint_as_float(v[12]), __uint_as_float(v[13]), __uint_as_float(v[14]), __uint_as_float(v[15]) };
     return r;
 }
 
@@ -232,6 +241,26 @@ __device__ __forceinline__ bool box_entry(const RayD& r, const float* lo, const 
 // (a child box is stored lo.x hi.x lo.y hi.y lo.z hi.z)
 __device__ __forceinline__ bool box_entry_left(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.a.x, n.a.z, n.b.x, n.a.y, n.a.w, n.b.y, t); }
 __device__ __forceinline__ bool box_entry_right(const RayD& r, const Rec64& n, float& t) { return box_entry(r, n.b.z, n.c.x, n.c.z, n.b.w, n.c.y, n.c.w, t); }
+// Both child boxes of a node record for a ray of the FAST CLASS in a scene whose root box (hence every box) lies within
+// +-FAST_BOUND: every slab product (plane - o) * (1 / d) is then finite and below 2e30 * 1e6 in magnitude (|d| > 1e-6
+// bounds the reciprocal), so none is a NaN, no zero-class override applies, and the parameter box_entry() reports is
+// always below FLT_MAX (the comparison its callers append is always true).  A slab's two planes are adjacent in the
+// record: one packed subtract and one packed multiply with the ray's scalars broadcast to both halves.
+__device__ __forceinline__ void box_pair_fast(const RayD& r, const Rec64& n, bool& vL, float& tL, bool& vR, float& tR)
+{
+    const f32x2 oX { r.o.x, r.o.x }, oY { r.o.y, r.o.y }, oZ { r.o.z, r.o.z };
+    const f32x2 iX { r.inv.x, r.inv.x }, iY { r.inv.y, r.inv.y }, iZ { r.inv.z, r.inv.z };
+    const f32x2 p0 = (n.a.xy - oX) * iX, p1 = (n.a.zw - oY) * iY, p2 = (n.b.xy - oZ) * iZ; // left box: x, y, z slab
+    const f32x2 p3 = (n.b.zw - oX) * iX, p4 = (n.c.xy - oY) * iY, p5 = (n.c.zw - oZ) * iZ; // right box
+    const float tinL = fmaxf(fmaxf(fminf(p0.x, p0.y), fminf(p1.x, p1.y)), fminf(p2.x, p2.y));
+    const float toutL = fminf(fminf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)), fmaxf(p2.x, p2.y));
+    const float tinR = fmaxf(fmaxf(fminf(p3.x, p3.y), fminf(p4.x, p4.y)), fminf(p5.x, p5.y));
+    const float toutR = fminf(fminf(fmaxf(p3.x, p3.y), fmaxf(p4.x, p4.y)), fmaxf(p5.x, p5.y));
+    vL = !(tinL > toutL) && !(toutL <= 0) && !is_zero(tinL);
+    vR = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR);
+    tL = tinL < 0 ? toutL : tinL;
+    tR = tinR < 0 ? toutR : tinR;
+}
 __device__ __forceinline__ int32_t node_ref_left(const Rec64& n) { return __float_as_int(n.d.x); }
 __device__ __forceinline__ int32_t node_ref_right(const Rec64& n) { return __float_as_int(n.d.y); }
 
@@ -337,6 +366,8 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
     int sp = 0;
     int32_t cur = S.rootRef;
     float curT = tRoot;
+    // the lanes that traverse together take the packed box test when all their rays are of the fast class
+    const bool fast = S.bounded && __builtin_amdgcn_ballot_w64(!r.fast) == 0;
     // "while-while": all lanes of the wave walk inner nodes until each holds a leaf (or has run out), then
     // all of them run their primitive tests together.  The per-lane visiting order is unchanged.
     while (true) {
@@ -348,8 +379,13 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
                 const Rec64 nd = load_rec(&S.nodes[cur]);
                 float tL, tR;
                 if (COUNT) cnt.box += 2;
-                const bool vL = box_entry_left(r, nd, tL) && tL < FLT_MAX;
-                const bool vR = box_entry_right(r, nd, tR) && tR < FLT_MAX;
+                bool vL, vR;
+                if (fast) {
+                    box_pair_fast(r, nd, vL, tL, vR, tR);
+                } else {
+                    vL = box_entry_left(r, nd, tL) && tL < FLT_MAX;
+                    vR = box_entry_right(r, nd, tR) && tR < FLT_MAX;
+                }
                 const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
                 if (vL && vR) {
                     const bool leftFirst = tL < tR;

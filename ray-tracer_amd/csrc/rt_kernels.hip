@@ -457,9 +457,6 @@ struct PairStack {
     }
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 // One 64-byte record per lane (byte offset `off` from `base`, any valid offset for lanes that need nothing),
 // fetched so that a load instruction touches 16 cache lines instead of 64: the four lanes of a quad fetch the
 // four 16-byte quarters of ONE record per load (the record of quad lane 0, then 1, 2, 3).  The data go to the
@@ -487,10 +484,15 @@ __device__ __forceinline__ void lds_fence()
 }
 
 
-// "entered at all" of both child boxes of a node for a ray none of whose direction components is in the
-// zero class: box_entry() followed by the caller's `t < FLT_MAX`.  a, b, c are the twelve consecutive floats of a
-// node record (two boxes, slab by slab): each slab is one packed subtract and one packed multiply with the ray's
-// origin component and reciprocal broadcast to both halves.
+// "entered at all" of both child boxes of a node — box_entry() followed by the caller's `t < FLT_MAX` — for a ray of
+// the FAST CLASS (RayD::fast) in a bounded scene (SceneView::bounded).  As box_pair_fast() explains, the parameter the
+// reference reports is then always below FLT_MAX and never a NaN: its last comparison is always true and the choice
+// between t_in and t_out that feeds it is not needed.  What is left of reference src/intersect.cpp:128-139 is the three
+// rejections.
+// a, b, c are the twelve consecutive floats of a node record (two boxes, slab by slab): each slab is one packed
+// subtract and one packed multiply with the ray's origin component and reciprocal broadcast to both halves.
+// A ray that has been answered is poisoned in the ray table (origin x = +inf): its x slab products are both -inf or
+// both +inf, which fails `t_out <= 0` or `t_in > t_out`, so it enters nothing without any flag test here.
 __device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, float ox, float oy, float oz, float ix, float iy, float iz, bool& left, bool& right)
 {
     const f32x2 oX { ox, ox }, oY { oy, oy }, oZ { oz, oz }, iX { ix, ix }, iY { iy, iy }, iZ { iz, iz };
@@ -504,8 +506,8 @@ __device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, float o
     const float toutL = fminf(fminf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)), fmaxf(p2.x, p2.y));
     const float tinR = fmaxf(fmaxf(fminf(p3.x, p3.y), fminf(p4.x, p4.y)), fminf(p5.x, p5.y));
     const float toutR = fminf(fminf(fmaxf(p3.x, p3.y), fmaxf(p4.x, p4.y)), fmaxf(p5.x, p5.y));
-    left = !(tinL > toutL) && !(toutL <= 0) && !is_zero(tinL) && (tinL < 0 ? toutL : tinL) < FLT_MAX;
-    right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR) && (tinR < 0 ? toutR : tinR) < FLT_MAX;
+    left = !(tinL > toutL) && !(toutL <= 0) && !is_zero(tinL);
+    right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR);
 }
 
 // value of `v` in lane `src` (any lane may ask for any lane's value; all lanes must be active)
@@ -550,14 +552,17 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
     const unsigned long long nPackets = (queued + raysPerPacket - 1) / raysPerPacket;
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
+    const bool sceneBounded = S.bounded != 0;
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
     // Packets of 64 consecutive queued queries come from a cursor.
     while (true) {
-        unsigned long long pk = 0;
-        if (lane == 0) pk = atomicAdd(&counters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
-        pk = __shfl(pk, 0, 64);
+        unsigned long long grabbed = 0;
+        if (lane == 0) grabbed = atomicAdd(&counters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
+        // (the same in every lane: kept in scalar registers)
+        const unsigned long long pk = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed))))
+            | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed >> 32)))) << 32);
         if (pk >= nPackets) break;
         // ---- this lane's query; the ones that pass the root gate start as pairs (ray, root)
         const unsigned long long qi = pk * raysPerPacket + uint32_t(lane);
@@ -606,8 +611,9 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
         rayO[lane] = f32x4 { r.o.x, r.o.y, r.o.z, __uint_as_float(zeroBits) };
         rayI[lane] = f32x4 { r.inv.x, r.inv.y, r.inv.z, 0.0f };
         const unsigned long long m = __builtin_amdgcn_ballot_w64(traced);
-        // some ray of the packet has a direction component in the zero class
-        const bool zeroClass = __builtin_amdgcn_ballot_w64(traced && zeroBits != 0u) != 0;
+        // The packet takes the general box test when some ray of it is outside the fast class of boxes_entered(): a
+        // direction component in the zero class or not finite, or an origin component beyond the bound (or NaN).
+        const bool zeroClass = !sceneBounded || __builtin_amdgcn_ballot_w64(traced && !r.fast) != 0;
         // one entry per group of G consecutive rays that has a ray past the root gate: (group, those rays, root)
         uint32_t count = 0, leafCount = 0;
         {
@@ -642,7 +648,6 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 // the rays' values are read before the node loads are issued so that both are in flight together
                 // (an LDS-class operation placed after them would be made to wait for them)
                 const uint32_t first = (e >> (32 - F::GROUP_BITS)) << F::LOG_G; // first ray of the group
-                const uint32_t mask = got ? (e >> F::REF_BITS) & F::ALL : 0u;
                 f32x4 ro[G], ri[G];
 #pragma unroll
                 for (int g = 0; g < G; g++) {
@@ -656,58 +661,59 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 else if (G == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0])::"memory");
                 else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0]), "+v"(ro[G > 2 ? 2 : 0]), "+v"(ri[G > 2 ? 2 : 0]), "+v"(ro[G > 3 ? 3 : 0]), "+v"(ri[G > 3 ? 3 : 0])::"memory");
                 // Straight-line from here: every lane evaluates the record its quad staged for it (lanes without an
-                // entry staged record 0; their outcome is masked).
+                // entry staged record 0 and have an empty ray mask).
                 const f32x4 a = staged[0], b = staged[1], c = staged[2];
                 const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
-                uint32_t mL = 0u, mR = 0u; // rays of the group that enter the left / right child
+                const int32_t refL = __float_as_int(refs.x), refR = __float_as_int(refs.y);
+                // which rays of the group enter the left / right child: as bits of the entries to push, in place
+                uint32_t bitsL = 0u, bitsR = 0u;
+                bool anyL = false, anyR = false;
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const uint32_t flags = __float_as_uint(ro[g].w);
-                    const bool live = ((mask >> g) & 1u) && !(flags & RAY_BLOCKED);
-                    if (COUNT && live) cnt.box += 2;
+                    const bool in = (e >> (F::REF_BITS + g)) & 1u; // (e = 0 in the lanes without an entry)
                     bool vL, vR;
                     if (!zeroClass) {
                         boxes_entered(a, b, c, ro[g].x, ro[g].y, ro[g].z, ri[g].x, ri[g].y, ri[g].z, vL, vR);
+                        if (COUNT && in && !(__float_as_uint(ro[g].w) & RAY_BLOCKED)) cnt.box += 2;
                     } else {
+                        const uint32_t flags = __float_as_uint(ro[g].w);
+                        const bool live = in && !(flags & RAY_BLOCKED);
+                        if (COUNT && live) cnt.box += 2;
                         RayD q;
                         q.o = make3(ro[g].x, ro[g].y, ro[g].z);
                         q.inv = make3(ri[g].x, ri[g].y, ri[g].z);
                         q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
                         float tL, tR;
-                        vL = box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX;
-                        vR = box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX;
+                        vL = live && box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX;
+                        vR = live && box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX;
                     }
-                    mL |= (vL && live) ? (1u << g) : 0u;
-                    mR |= (vR && live) ? (1u << g) : 0u;
+                    const bool gL = vL && in, gR = vR && in;
+                    anyL = anyL || gL;
+                    anyR = anyR || gR;
+                    bitsL |= gL ? (1u << (F::REF_BITS + g)) : 0u;
+                    bitsR |= gR ? (1u << (F::REF_BITS + g)) : 0u;
                 }
-                // One code per child: the child reference when some ray of the group enters the box (inner node: >= 0 as
-                // a signed number; leaf: ~slot, above 0x80000000 as an unsigned one), else NO_CHILD = 0x80000000, which
-                // is neither.  Every vote below is then a single comparison of that register.
-                constexpr uint32_t NO_CHILD = 0x80000000u;
-                const uint32_t cL = mL ? __float_as_uint(refs.x) : NO_CHILD;
-                const uint32_t cR = mR ? __float_as_uint(refs.y) : NO_CHILD;
                 const uint32_t tag = e & ~((1u << (32 - F::GROUP_BITS)) - 1u); // the group index, in place
-                const uint32_t eL = tag | (mL << F::REF_BITS), eR = tag | (mR << F::REF_BITS);
-                // children that are inner nodes go back on the stack, those of higher lanes higher
-                const bool iL = int32_t(cL) >= 0, iR = int32_t(cR) >= 0;
+                // children that are inner nodes (reference >= 0) go back on the stack, those of higher lanes higher
+                const bool iL = anyL && refL >= 0, iR = anyR && refR >= 0;
                 const unsigned long long bL = __builtin_amdgcn_ballot_w64(iL), bR = __builtin_amdgcn_ballot_w64(iR);
                 const uint32_t nL = uint32_t(__popcll(bL)), nR = uint32_t(__popcll(bR));
                 const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(bR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bR),
                     __builtin_amdgcn_mbcnt_hi(uint32_t(bL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bL), count))));
                 if (inLds) {
-                    if (iL) pool.lds[at] = eL | cL;
-                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = eR | cR;
+                    if (iL) pool.lds[at] = tag | bitsL | uint32_t(refL);
+                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | bitsR | uint32_t(refR);
                 } else {
-                    if (iL) pool.put(at, eL | cL);
-                    if (iR) pool.put(at + (iL ? 1u : 0u), eR | cR);
+                    if (iL) pool.put(at, tag | bitsL | uint32_t(refL));
+                    if (iR) pool.put(at + (iL ? 1u : 0u), tag | bitsR | uint32_t(refR));
                 }
                 count += nL + nR;
-                // children that are leaves: to the primitive pool
-                const bool lL = cL > NO_CHILD, lR = cR > NO_CHILD;
+                // children that are leaves (reference = ~slot): to the primitive pool
+                const bool lL = anyL && refL < 0, lR = anyR && refR < 0;
                 const unsigned long long bLL = __builtin_amdgcn_ballot_w64(lL), bLR = __builtin_amdgcn_ballot_w64(lR);
-                if (lL) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLL), leafCount))] = eL | ~cL;
+                if (lL) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLL), leafCount))] = tag | bitsL | uint32_t(~refL);
                 leafCount += uint32_t(__popcll(bLL));
-                if (lR) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLR), leafCount))] = eR | ~cR;
+                if (lR) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLR), leafCount))] = tag | bitsR | uint32_t(~refR);
                 leafCount += uint32_t(__popcll(bLR));
             } else {
                 // primitive step: up to 64 (group, leaf) entries
@@ -736,11 +742,10 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                         // the leaf's first record is staged; further ones (leaves cut off by the level limit) come one by one
                         Rec64 p;
                         if (firstRec) {
-                            const f32x4 q0 = staged[0], q1 = staged[1], q2 = staged[2], q3 = staged[3];
-                            p.a = make_float4(q0.x, q0.y, q0.z, q0.w);
-                            p.b = make_float4(q1.x, q1.y, q1.z, q1.w);
-                            p.c = make_float4(q2.x, q2.y, q2.z, q2.w);
-                            p.d = make_float4(q3.x, q3.y, q3.z, q3.w);
+                            p.a = staged[0];
+                            p.b = staged[1];
+                            p.c = staged[2];
+                            p.d = staged[3];
                             firstRec = false;
                         } else {
                             p = load_rec(&S.prims[slot]);
@@ -752,8 +757,10 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                             if (COUNT) cnt.tri++;
                             float t;
                             if (triangle_hit(q[g], p, tBound, t)) {
+                                // answered: flagged, and poisoned for the fast box test (see boxes_entered)
                                 atomicOr(flag_word(first + uint32_t(g)), RAY_BLOCKED);
-                                mask &= ~(1u << g); // this ray is answered
+                                *reinterpret_cast<float*>(rayO + first + uint32_t(g)) = __builtin_inff();
+                                mask &= ~(1u << g);
                             }
                         }
                         slot++;

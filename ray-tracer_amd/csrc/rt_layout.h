@@ -81,6 +81,7 @@ struct SceneView {
     int32_t hasSkybox;
     int32_t hasSpheres;
     int32_t stackDepth; // entries a traversal stack can need (number of tree levels)
+    int32_t bounded;    // the root box (hence every box) lies within +-1e30: the packed box tests apply
 };
 
 } // namespace rt
