@@ -296,6 +296,9 @@ def main():
                 "all_kernels": {"kernel_ms": avg_kernel_s * 1e3, "primary_ms": primary_ms / args.steps, "shadow_ms": shadow_ms / args.steps,
                                 "cull_ms": cull_ms / args.steps, "shade_ms": shade_ms / args.steps,
                                 "own_tests_bytes": algorithmic_bytes(cst, my_pixels), "own_tests_flops": algorithmic_flops(cst)},
+                "stream_steps": {"packets": cst.stream_packets, "box_steps": cst.stream_box_steps, "primitive_steps": cst.stream_prim_steps,
+                                 "entries_per_box_step": cst.stream_entries / max(1, cst.stream_box_steps),
+                                 "note": "shadow pass of the counted frame: packets of 64 queries, steps of the pair stream"},
                 "box_tests_per_ray": cst.box_tests / max(1, cst.total_rays()),
                 "triangle_tests_per_ray": cst.triangle_tests / max(1, cst.total_rays()),
             },

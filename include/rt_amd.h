@@ -174,6 +174,9 @@ typedef struct rt_stats {
     /* calls of the reference's getFinalColor (src/render.cpp:18-80) that were evaluated as nodes of wavefront passes
      * (one generation of the recursion per pass); 0 when the frame ran in the per-lane kernels */
     uint64_t wavefront_nodes;
+    /* shadow pass (pair stream), only with rt_params.count_tests: packets of 64 queries, box steps (up to 64 stack
+     * entries each), primitive steps, stack entries popped by the box steps */
+    uint64_t stream_packets, stream_box_steps, stream_prim_steps, stream_entries;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device copy of geometry, materials, textures, skybox */

@@ -196,6 +196,10 @@ class Stats(C.Structure):
         ("cull_ms", C.c_float),
         ("culled_shadow_rays", C.c_uint64),
         ("wavefront_nodes", C.c_uint64),
+        ("stream_packets", C.c_uint64),
+        ("stream_box_steps", C.c_uint64),
+        ("stream_prim_steps", C.c_uint64),
+        ("stream_entries", C.c_uint64),
     ]
 
     def total_rays(self):

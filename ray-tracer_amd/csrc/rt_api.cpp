@@ -275,6 +275,7 @@ rt_status upload_bvh(rt_bvh* b)
     std::memcpy(v.rootHi, flat.rootHi, 12);
     v.rootRef = flat.rootRef;
     v.numPrims = int32_t(flat.prims.size());
+    v.numNodes = int32_t(flat.nodes.size());
     v.numMeshes = int32_t(scene->host.meshes.size());
     v.hasSkybox = scene->host.skybox.size() == 6;
     v.hasSpheres = !scene->host.spheres.empty();
@@ -835,6 +836,10 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         stats->shadow_triangle_tests = h[STAT_SHADOW_TRI];
         stats->culled_shadow_rays = h[STAT_CULLED];
         stats->wavefront_nodes = wavefrontNodes;
+        stats->stream_packets = h[STAT_STREAM_PACKETS];
+        stats->stream_box_steps = h[STAT_STREAM_BOX_STEPS];
+        stats->stream_prim_steps = h[STAT_STREAM_PRIM_STEPS];
+        stats->stream_entries = h[STAT_STREAM_ENTRIES];
         if (splitRecorded) {
             RT_HIP(hipEventElapsedTime(&stats->primary_ms, b->evStart, b->evSplit[0]));
             RT_HIP(hipEventElapsedTime(&stats->cull_ms, b->evSplit[0], b->evSplit[1]));

@@ -6,7 +6,8 @@
 
 namespace rt {
 
-enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_SHADOW_BOX, STAT_SHADOW_TRI, STAT_CULLED, STAT_COUNT };
+enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_SHADOW_BOX, STAT_SHADOW_TRI, STAT_CULLED,
+    STAT_STREAM_PACKETS, STAT_STREAM_BOX_STEPS, STAT_STREAM_PRIM_STEPS, STAT_STREAM_ENTRIES, STAT_COUNT };
 
 // Renders the P.rowsLocal local rows of the call: the traversal/shading passes, then (more than one sample per pixel)
 // the resolve pass.  `afterPasses`, when not null, is recorded between the two.  `split`, when not null, points

@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
     const PairStack pool { leafPool + STREAM_LEAF_CAP, P.pairSpill + size_t(blockIdx.x) * P.pairSpillEntries, uint32_t(P.pairStackLds) };
     const int lane = int(threadIdx.x);
     Counts cnt;
+    uint32_t nPacketsDone = 0, nBoxSteps = 0, nPrimSteps = 0, nEntries = 0; // (test-counting build only; wave-uniform)
     const SceneView& S = P.scene;
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     unsigned long long* const counters = PRIMARY ? P.primaryCounters : P.queueCounters;
@@ -553,6 +554,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
     const bool sceneBounded = S.bounded != 0;
+    const uint32_t lastNode = S.numNodes > 0 ? uint32_t(S.numNodes - 1) : 0u, lastPrim = S.numPrims > 0 ? uint32_t(S.numPrims - 1) : 0u;
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
@@ -564,6 +566,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
         const unsigned long long pk = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed))))
             | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed >> 32)))) << 32);
         if (pk >= nPackets) break;
+        if (COUNT) nPacketsDone++;
         // ---- this lane's query; the ones that pass the root gate start as pairs (ray, root)
         const unsigned long long qi = pk * raysPerPacket + uint32_t(lane);
         const bool have = uint32_t(lane) < raysPerPacket && qi < queued;
@@ -636,6 +639,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
             if (count && leafCount < 64u) {
                 // box step: the top 64 entries
                 const uint32_t k = count < 64u ? count : 64u;
+                if (COUNT) { nBoxSteps++; nEntries += k; }
                 const bool got = uint32_t(lane) < k;
                 const bool inLds = count - k + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
                 uint32_t e = 0u;
@@ -655,7 +659,8 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                     ri[g] = rayI[first + uint32_t(g)];
                 }
                 asm volatile("" ::: "memory");
-                stage_records(S.nodes, (e & F::REF_MASK) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
+                // (the index is clamped to the table: a fetch must stay inside it whatever an entry holds)
+                stage_records(S.nodes, min(e & F::REF_MASK, lastNode) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
                 // the ray values are named as operands of the wait so that their LDS reads are issued ahead of it
                 if (G == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0])::"memory");
                 else if (G == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0])::"memory");
@@ -718,53 +723,53 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
             } else {
                 // primitive step: up to 64 (group, leaf) entries
                 const uint32_t k = leafCount < 64u ? leafCount : 64u;
+                if (COUNT) nPrimSteps++;
                 const bool got = uint32_t(lane) < k;
                 const uint32_t e = got ? leafPool[leafCount - 1u - uint32_t(lane)] : 0u;
                 leafCount -= k;
                 const uint32_t first = (e >> (32 - F::GROUP_BITS)) << F::LOG_G;
-                uint32_t mask = got ? (e >> F::REF_BITS) & F::ALL : 0u;
-                RayD q[G];
-#pragma unroll
-                for (int g = 0; g < G; g++) {
-                    const f32x4 o = rayO[first + uint32_t(g)];
-                    q[g].o = make3(o.x, o.y, o.z);
-                    q[g].d = make3(lane_value(first + uint32_t(g), r.d.x), lane_value(first + uint32_t(g), r.d.y), lane_value(first + uint32_t(g), r.d.z));
-                    if (__float_as_uint(o.w) & RAY_BLOCKED) mask &= ~(1u << g);
-                }
+                const uint32_t mask = got ? (e >> F::REF_BITS) & F::ALL : 0u;
                 asm volatile("" ::: "memory");
-                stage_records(S.prims, (e & F::REF_MASK) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
+                stage_records(S.prims, min(e & F::REF_MASK, lastPrim) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
                 stage_wait();
-                if (mask) {
-                    int32_t slot = int32_t(e & F::REF_MASK);
-                    int32_t more;
-                    bool firstRec = true;
-                    do {
-                        // the leaf's first record is staged; further ones (leaves cut off by the level limit) come one by one
-                        Rec64 p;
-                        if (firstRec) {
-                            p.a = staged[0];
-                            p.b = staged[1];
-                            p.c = staged[2];
-                            p.d = staged[3];
-                            firstRec = false;
-                        } else {
-                            p = load_rec(&S.prims[slot]);
-                        }
-                        more = prim_more(p);
-#pragma unroll
-                        for (int g = 0; g < G; g++) {
-                            if (!((mask >> g) & 1u)) continue;
+                // The rays of the group one after the other, as a loop that is NOT unrolled: one copy of the triangle test
+                // in the code, and only one ray's values in registers at a time.
+#pragma nounroll
+                for (int g = 0; g < G; g++) {
+                    const uint32_t ray = first + uint32_t(g);
+                    const f32x4 o = rayO[ray];
+                    RayD q;
+                    q.o = make3(o.x, o.y, o.z);
+                    q.d = make3(lane_value(ray, r.d.x), lane_value(ray, r.d.y), lane_value(ray, r.d.z));
+                    bool live = ((mask >> g) & 1u) && !(__float_as_uint(o.w) & RAY_BLOCKED);
+                    if (live) {
+                        int32_t slot = int32_t(e & F::REF_MASK);
+                        int32_t more;
+                        bool firstRec = true;
+                        do {
+                            // the leaf's first record is staged; further ones (leaves cut off by the level limit) come one by one
+                            Rec64 p;
+                            if (firstRec) {
+                                p.a = staged[0];
+                                p.b = staged[1];
+                                p.c = staged[2];
+                                p.d = staged[3];
+                                firstRec = false;
+                            } else {
+                                p = load_rec(&S.prims[slot]);
+                            }
+                            more = prim_more(p);
                             if (COUNT) cnt.tri++;
                             float t;
-                            if (triangle_hit(q[g], p, tBound, t)) {
+                            if (triangle_hit(q, p, tBound, t)) {
                                 // answered: flagged, and poisoned for the fast box test (see boxes_entered)
-                                atomicOr(flag_word(first + uint32_t(g)), RAY_BLOCKED);
-                                *reinterpret_cast<float*>(rayO + first + uint32_t(g)) = __builtin_inff();
-                                mask &= ~(1u << g);
+                                atomicOr(flag_word(ray), RAY_BLOCKED);
+                                *reinterpret_cast<float*>(rayO + ray) = __builtin_inff();
+                                live = false;
                             }
-                        }
-                        slot++;
-                    } while (more > 0 && mask);
+                            slot++;
+                        } while (more > 0 && live);
+                    }
                 }
             }
             __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
@@ -803,6 +808,12 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
         lds_fence();
     }
     flush_counts(cnt, P.stats, !PRIMARY);
+    if (COUNT && !PRIMARY && P.stats && lane == 0) {
+        atomicAdd(&P.stats[STAT_STREAM_PACKETS], (unsigned long long)nPacketsDone);
+        atomicAdd(&P.stats[STAT_STREAM_BOX_STEPS], (unsigned long long)nBoxSteps);
+        atomicAdd(&P.stats[STAT_STREAM_PRIM_STEPS], (unsigned long long)nPrimSteps);
+        atomicAdd(&P.stats[STAT_STREAM_ENTRIES], (unsigned long long)nEntries);
+    }
 }
 
 // Shade pass: one lane per queued hit — direct lighting with the visibility bits of the shadow pass

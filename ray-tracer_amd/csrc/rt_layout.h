@@ -77,6 +77,7 @@ struct SceneView {
     float rootLo[3], rootHi[3];
     int32_t rootRef;    // child-style reference of the root node
     int32_t numPrims;
+    int32_t numNodes;   // inner-node records
     int32_t numMeshes;
     int32_t hasSkybox;
     int32_t hasSpheres;
