@@ -177,6 +177,9 @@ typedef struct rt_stats {
     /* shadow pass (pair stream), only with rt_params.count_tests: packets of 64 queries, box steps (up to 64 stack
      * entries each), primitive steps, stack entries popped by the box steps */
     uint64_t stream_packets, stream_box_steps, stream_prim_steps, stream_entries;
+    /* duration of the second, small shadow kernel of a pass (the lighting of the camera rays that were finished on the
+     * library's own stream beside the main lighting round); shadow_ms is the main round's kernel alone */
+    float shadow_b_ms;
 } rt_stats;
 
 typedef struct rt_scene rt_scene; /* device copy of geometry, materials, textures, skybox */
@@ -226,12 +229,14 @@ rt_status rt_visibility_batch(const rt_bvh* bvh, const rt_ray* rays_with_hit_t, 
  * top-most of those rows first — i.e. the slice of the Screen buffer those rows occupy; host pointer when
  * device_ptr == 0, device pointer otherwise.  Bloom, which needs the whole frame, is NOT applied here even
  * if features->bloom is set: call rt_bloom on the assembled frame.
- * Calls on one rt_bvh are serialised by the library (several threads may render from one hierarchy, as the reference's
- * per-camera threads do, src/main.cpp:533-552).  With a host frame or a stats pointer the call returns when the frame
- * is complete.  With a device frame and stats == NULL it only queues the work on `stream` and returns: the per-call
- * scratch of the rt_bvh is then still in use, so the next call on that rt_bvh must be queued on the same stream or come
- * after the caller has waited for it.  The library may run part of a call on a stream of its own; that stream is
- * joined into `stream` before the call's work on `stream` ends. */
+ * Several threads may render from one rt_bvh at the same time, as the reference's per-camera threads do
+ * (src/main.cpp:533-552): every call works on a scratch set of its own (queues, sample planes, counters; up to eight
+ * sets per rt_bvh, kept until rt_bvh_destroy; a ninth concurrent call waits for a set).  With a host frame or a stats
+ * pointer the call returns when the frame is complete; a host-frame call that names no stream runs on a stream of its
+ * scratch set, so such calls overlap on the GPU.  With a device frame and stats == NULL the call only queues its work on
+ * `stream` and returns; the scratch set stays reserved until that work has finished (calls queued on the same stream
+ * reuse it, stream order keeps them apart).  The library may run part of a call on a second stream of its own; that
+ * stream is joined into the call's stream before the call's work there ends. */
 rt_status rt_render(const rt_bvh* bvh, const rt_camera* camera, const rt_light* lights, int32_t n_lights,
     const rt_features* features, const rt_params* params, int32_t width, int32_t height, int32_t row_begin,
     int32_t row_end, float* out_rgb, int32_t device_ptr, void* stream, rt_stats* stats);

@@ -200,6 +200,7 @@ class Stats(C.Structure):
         ("stream_box_steps", C.c_uint64),
         ("stream_prim_steps", C.c_uint64),
         ("stream_entries", C.c_uint64),
+        ("shadow_b_ms", C.c_float),
     ]
 
     def total_rays(self):

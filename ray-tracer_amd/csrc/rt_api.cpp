@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -81,6 +83,52 @@ struct rt_scene {
     ImageRec skybox[6] = {};
 };
 
+// Device memory, events and the second stream one rt_render call works with.  A call takes a set from its hierarchy's
+// pool and gives it back when it returns, so calls on one rt_bvh from several threads (the reference renders one camera
+// per thread from one BvhInterface, src/main.cpp:533-552) run side by side, each on its own set.
+struct RenderScratch {
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux;
+    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
+    // second stream (and its fork / join events) on which a direct-lighting pass finishes its long camera rays, and the
+    // two marks around that stream's shadow kernel
+    hipStream_t auxStream = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr, evShadowB[2] = { nullptr, nullptr };
+    // stream of the set's own: a call that hands over host pixels and names no stream runs on it instead of the null
+    // stream (such a call returns only when its frame is complete, so nothing else can be ordered against it)
+    hipStream_t ownStream = nullptr;
+    // a call that returned without waiting (device frame, no statistics) leaves the set in use by `lastStream` until `done`
+    hipEvent_t done = nullptr;
+    hipStream_t lastStream = nullptr;
+    bool pending = false, busy = false;
+
+    hipError_t init()
+    {
+        hipError_t e;
+        for (hipEvent_t* ev : { &evStart, &evMid, &evStop, &evSplit[0], &evSplit[1], &evSplit[2], &evSplit[3], &evShadowB[0], &evShadowB[1] })
+            if ((e = hipEventCreate(ev)) != hipSuccess) return e;
+        for (hipEvent_t* ev : { &evFork, &evJoin, &done })
+            if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return e;
+        if ((e = hipStreamCreateWithFlags(&auxStream, hipStreamNonBlocking)) != hipSuccess) return e;
+        return hipStreamCreateWithFlags(&ownStream, hipStreamNonBlocking);
+    }
+    ~RenderScratch()
+    {
+        if (pending && done) (void)hipEventSynchronize(done);
+        if (auxStream) {
+            (void)hipStreamSynchronize(auxStream); // (joined into the caller's stream at the end of every pass; nothing should be left)
+            (void)hipStreamDestroy(auxStream);
+        }
+        if (ownStream) {
+            (void)hipStreamSynchronize(ownStream);
+            (void)hipStreamDestroy(ownStream);
+        }
+        for (DevBuf* d : { &stats, &frame, &queue, &queueCounters, &visibility, &shadowQueue, &pairSpill, &samples, &dofFlags, &wfRays, &wfNodes, &wfMeta, &wfValue, &wfHits, &wfHitNode, &wfGlossy, &gaveUpQueue, &pairSpillAux })
+            d->release();
+        for (hipEvent_t ev : { evStart, evMid, evStop, evSplit[0], evSplit[1], evSplit[2], evSplit[3], evShadowB[0], evShadowB[1], evFork, evJoin, done })
+            if (ev) (void)hipEventDestroy(ev);
+    }
+};
+
 struct rt_bvh {
     rt_scene* scene = nullptr;
     HostBvh host;
@@ -89,14 +137,14 @@ struct rt_bvh {
     bool deviceSorted = false; // the per-level sorts of the build ran on the GPU
     DevBuf nodes, prims, attrs, primOrder;
     SceneView view {};
-    // per-call scratch, guarded by `lock` (the reference lets several threads render from one BvhInterface)
+    // `lock` guards the upload and the buffers of the batch entry points (those calls run one at a time)
     std::mutex lock;
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, rays, hits, misc, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy;
-    hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
-    // second stream (and its fork / join events) on which a direct-lighting pass finishes its long camera rays
-    hipStream_t auxStream = nullptr;
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
-    DevBuf gaveUpQueue, pairSpillAux;
+    DevBuf rays, hits, misc;
+    // scratch sets of rt_render, guarded by `poolLock`
+    enum { MAX_SCRATCH_SETS = 8 };
+    std::mutex poolLock;
+    std::condition_variable poolFree;
+    std::vector<std::unique_ptr<RenderScratch>> pool;
 };
 
 namespace {
@@ -252,16 +300,6 @@ rt_status upload_bvh(rt_bvh* b)
     RT_HIP(upload(b->prims, flat.prims));
     RT_HIP(upload(b->attrs, flat.attrs));
     RT_HIP(upload(b->primOrder, flat.primOrder));
-    RT_HIP(b->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
-    // (a retry after a partial failure keeps the events it already has)
-    if (!b->evStart) RT_HIP(hipEventCreate(&b->evStart));
-    if (!b->evMid) RT_HIP(hipEventCreate(&b->evMid));
-    for (hipEvent_t& e : b->evSplit)
-        if (!e) RT_HIP(hipEventCreate(&e));
-    if (!b->evStop) RT_HIP(hipEventCreate(&b->evStop));
-    if (!b->auxStream) RT_HIP(hipStreamCreateWithFlags(&b->auxStream, hipStreamNonBlocking));
-    if (!b->evFork) RT_HIP(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
-    if (!b->evJoin) RT_HIP(hipEventCreateWithFlags(&b->evJoin, hipEventDisableTiming));
     SceneView& v = b->view;
     v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
     v.prims = static_cast<const PrimRec*>(b->prims.ptr);
@@ -508,19 +546,8 @@ int32_t rt_bvh_device_sorted(const rt_bvh* b) { return b && b->deviceSorted ? 1 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->stats, &b->frame, &b->queue, &b->queueCounters, &b->visibility, &b->shadowQueue, &b->pairSpill, &b->samples, &b->dofFlags, &b->rays, &b->hits, &b->misc, &b->wfRays, &b->wfNodes, &b->wfMeta, &b->wfValue, &b->gaveUpQueue, &b->pairSpillAux, &b->wfHits, &b->wfHitNode, &b->wfGlossy })
-        d->release();
-    if (b->evStart) (void)hipEventDestroy(b->evStart);
-    if (b->evMid) (void)hipEventDestroy(b->evMid);
-    for (hipEvent_t e : b->evSplit)
-        if (e) (void)hipEventDestroy(e);
-    if (b->evStop) (void)hipEventDestroy(b->evStop);
-    if (b->evFork) (void)hipEventDestroy(b->evFork);
-    if (b->evJoin) (void)hipEventDestroy(b->evJoin);
-    if (b->auxStream) {
-        (void)hipStreamSynchronize(b->auxStream); // (joined into the caller's stream at the end of every pass; nothing should be left)
-        (void)hipStreamDestroy(b->auxStream);
-    }
+    b->pool.clear(); // (waits for whatever a call left queued on a set)
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->rays, &b->hits, &b->misc }) d->release();
     delete b;
 }
 
@@ -630,6 +657,64 @@ rt_status rt_render_blocks(const rt_bvh* cb, const rt_camera* camera, const rt_l
 }
 
 namespace {
+
+// Takes a scratch set of `b` for a call that will queue its work on `stream`: one nobody holds and whose last call has
+// finished or was queued on the same stream (stream order then keeps the two apart); otherwise a new one, up to
+// MAX_SCRATCH_SETS; otherwise it waits for one.  Released by the lease's destructor.
+struct ScratchLease {
+    rt_bvh* b = nullptr;
+    RenderScratch* set = nullptr;
+    hipStream_t stream = nullptr;
+    bool waited = false; // the call has waited for its work: the set is idle when it is given back
+    ~ScratchLease()
+    {
+        if (!set) return;
+        std::lock_guard<std::mutex> guard(b->poolLock);
+        set->pending = !waited && hipEventRecord(set->done, stream) == hipSuccess;
+        set->lastStream = stream;
+        set->busy = false;
+        b->poolFree.notify_one();
+    }
+};
+rt_status acquire_scratch(rt_bvh* b, hipStream_t stream, bool ownStream, ScratchLease& lease)
+{
+    std::unique_lock<std::mutex> guard(b->poolLock);
+    lease.b = b;
+    while (true) {
+        RenderScratch* idle = nullptr;
+        RenderScratch* queued = nullptr;
+        for (auto& s : b->pool) {
+            if (s->busy) continue;
+            if (s->pending && !ownStream && s->lastStream == stream) s->pending = false; // the new work queues up behind the old
+            if (s->pending && hipEventQuery(s->done) == hipSuccess) s->pending = false;
+            if (!s->pending) {
+                idle = s.get();
+                break;
+            }
+            queued = s.get();
+        }
+        if (!idle && int(b->pool.size()) < int(rt_bvh::MAX_SCRATCH_SETS)) {
+            auto fresh = std::make_unique<RenderScratch>();
+            const hipError_t e = fresh->init();
+            if (e != hipSuccess) return hip_fail(e, "rt_render: creating the events and streams of a scratch set");
+            idle = fresh.get();
+            b->pool.push_back(std::move(fresh));
+        }
+        if (!idle && queued) {
+            RT_HIP(hipEventSynchronize(queued->done));
+            queued->pending = false;
+            idle = queued;
+        }
+        if (idle) {
+            idle->busy = true;
+            lease.set = idle;
+            lease.stream = ownStream ? idle->ownStream : stream;
+            return RT_OK;
+        }
+        b->poolFree.wait(guard); // every set is held by a running call
+    }
+}
+
 rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
     const rt_params* params, int32_t width, int32_t height, int32_t rowsLocal, int32_t rowTop, int32_t rowBlock, int32_t blockStride,
     float* outRgb, int32_t devicePtr, void* stream, rt_stats* stats)
@@ -645,13 +730,18 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (rowsLocal == 0) return RT_OK;
 
-    std::lock_guard<std::mutex> guard(b->lock);
     {
+        std::lock_guard<std::mutex> guard(b->lock);
         rt_status up = upload_bvh(b);
         if (up != RT_OK) return up;
     }
     RT_HIP(hipSetDevice(b->scene->device));
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    // a call that returns host pixels and names no stream gets the stream of its scratch set, so that such calls from
+    // several threads overlap on the GPU instead of queueing up on the null stream
+    ScratchLease lease;
+    if ((st = acquire_scratch(b, static_cast<hipStream_t>(stream), !devicePtr && stream == nullptr, lease)) != RT_OK) return st;
+    RenderScratch* w = lease.set;
+    hipStream_t s = lease.stream;
     const size_t nPix = size_t(rowsLocal) * size_t(width);
 
     FrameParams P;
@@ -703,20 +793,27 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     else if (features->depth_of_field) spp = params->dof_samples + 1;
     P.samplesPerPixel = spp;
     if (spp > 1) {
-        RT_HIP(b->samples.reserve(nPix * size_t(spp) * 12));
-        P.samples = static_cast<float*>(b->samples.ptr);
+        RT_HIP(w->samples.reserve(nPix * size_t(spp) * 12));
+        P.samples = static_cast<float*>(w->samples.ptr);
     }
     if (features->depth_of_field && !features->multiple_rays) {
-        RT_HIP(b->dofFlags.reserve(nPix));
-        P.dofFlags = static_cast<uint8_t*>(b->dofFlags.ptr);
+        RT_HIP(w->dofFlags.reserve(nPix));
+        P.dofFlags = static_cast<uint8_t*>(w->dofFlags.ptr);
     } else {
         P.f.depth_of_field = 0; // the reference ignores it when supersampling is on (render.cpp:96-98)
     }
     {
-        // hit queue of the two-kernel path: one 16-byte entry per (pixel, sample) of a pass, passes sized to
-        // at most 64 Mi entries (1 GiB)
+        // Hit queue of the queue passes: one 16-byte entry per (pixel, sample) of a pass.  Every entry has a visibility
+        // byte and a 4-byte work item per shadow-casting light sample, so the number of entries is bounded by the light
+        // sampling too: items = entries x samples per hit stays below 2^32 (item numbers are 32 bits wide) and below
+        // 2^30 (5 GB of visibility bytes and work items).  A pass takes whole sample planes, so the queue holds at least
+        // one entry per pixel; frames beyond that are refused below.
+        const size_t perHit = size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1);
+        const size_t itemBudget = size_t(1) << 30;
         const size_t want = nPix * size_t(spp);
-        size_t cap = want < (size_t(64) << 20) ? want : (nPix > (size_t(64) << 20) ? nPix : (size_t(64) << 20));
+        size_t cap = want < (size_t(64) << 20) ? want : (size_t(64) << 20);
+        if (cap > itemBudget / perHit) cap = itemBudget / perHit;
+        if (cap < nPix) cap = nPix;
         // Wavefront evaluation of bounce features: node buffers for the call trees of a chunk of pixel samples, and a
         // hit queue with an entry per node.  By default only frames with glossy reflection take it (their fan-out is what
         // a lane of the general kernel cannot keep up with); RT_WAVEFRONT=1 sends every frame with a bounce feature
@@ -725,104 +822,123 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             const char* e = std::getenv("RT_WAVEFRONT");
             return e ? std::atoi(e) : -1;
         }();
+        static const long forcedNodes = [] {
+            const char* e = std::getenv("RT_WAVEFRONT_NODES"); // test knob: a small node buffer makes chunks overflow and split
+            return e ? std::atol(e) : 0L;
+        }();
         const bool bounce = features->recursive || features->glossy || features->transparency || (features->environment_mapping && params->enabled_refl_map);
         if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && features->glossy))) {
+            // at most 24 Mi nodes (2 GB of node records), and no more than the hit queue may hold entries for: a chunk has
+            // at most `nodes` roots and `nodes` nodes, each with at most one hit entry
+            size_t nodeLimit = size_t(24) << 20;
+            if (nodeLimit > itemBudget / perHit / 2) nodeLimit = itemBudget / perHit / 2;
             size_t nodes = 4 * want;
             if (nodes < (size_t(1) << 20)) nodes = size_t(1) << 20;
-            if (features->glossy) {
-                // room for the largest call tree one pixel sample can have (filter^depth glossy samples at the deepest level),
-                // so that a chunk of a single sample always fits
-                size_t worst = 1, level = 1;
-                for (int d = 0; d < params->ray_depth && worst < (size_t(24) << 20); d++) {
+            // the largest call tree one pixel sample can have (filter^depth glossy samples at the deepest level; see-through
+            // continuations between the glossy levels add a few each): a chunk of a single sample must fit twice over
+            size_t worst = 1, level = 1;
+            if (features->glossy)
+                for (int d = 0; d < params->ray_depth && worst <= nodeLimit; d++) {
                     level *= size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1);
                     worst += level;
                 }
-                if (nodes < 2 * worst) nodes = 2 * worst; // (see-through continuations between the glossy levels add a few each)
-            }
-            if (nodes > (size_t(24) << 20)) nodes = size_t(24) << 20;
-            static const long forcedNodes = [] {
-                const char* e = std::getenv("RT_WAVEFRONT_NODES"); // test knob: a small node buffer makes chunks overflow and split
-                return e ? std::atol(e) : 0L;
-            }();
+            if (nodes < 2 * worst) nodes = 2 * worst;
+            // A frame whose single-sample tree does not fit the limit is rendered by the per-lane kernel (no node buffer
+            // is set up), which needs no memory per call; the two evaluation orders give the same frame.
+            const bool fitsLimit = 2 * worst <= nodeLimit;
+            if (nodes > nodeLimit) nodes = nodeLimit;
             if (forcedNodes > 0) nodes = size_t(forcedNodes < 256 ? 256 : forcedNodes);
-            const size_t calls = nodes / size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1) + 64;
-            RT_HIP(b->wfRays.reserve(nodes * sizeof(WfRay)));
-            RT_HIP(b->wfNodes.reserve(nodes * sizeof(WfNode)));
-            RT_HIP(b->wfMeta.reserve(nodes * sizeof(uint32_t)));
-            RT_HIP(b->wfValue.reserve(nodes * 12));
-            RT_HIP(b->wfHits.reserve(nodes * sizeof(uint32_t)));
-            RT_HIP(b->wfHitNode.reserve(2 * nodes * sizeof(uint32_t))); // one per hit-queue entry
-            RT_HIP(b->wfGlossy.reserve(calls * sizeof(WfGlossy)));
-            P.wfRays = static_cast<WfRay*>(b->wfRays.ptr);
-            P.wfNodes = static_cast<WfNode*>(b->wfNodes.ptr);
-            P.wfMeta = static_cast<uint32_t*>(b->wfMeta.ptr);
-            P.wfValue = static_cast<float*>(b->wfValue.ptr);
-            P.wfHits = static_cast<uint32_t*>(b->wfHits.ptr);
-            P.wfHitNode = static_cast<uint32_t*>(b->wfHitNode.ptr);
-            P.wfGlossy = static_cast<WfGlossy*>(b->wfGlossy.ptr);
-            P.wfCapacity = uint32_t(nodes);
-            P.wfGlossyCapacity = uint32_t(calls);
-            if (cap < 2 * nodes) cap = 2 * nodes; // a chunk has at most `nodes` roots and `nodes` nodes, each with at most one hit entry
+            if (fitsLimit || forcedNodes > 0) {
+                const size_t calls = nodes / size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1) + 64;
+                RT_HIP(w->wfRays.reserve(nodes * sizeof(WfRay)));
+                RT_HIP(w->wfNodes.reserve(nodes * sizeof(WfNode)));
+                RT_HIP(w->wfMeta.reserve(nodes * sizeof(uint32_t)));
+                RT_HIP(w->wfValue.reserve(nodes * 12));
+                RT_HIP(w->wfHits.reserve(nodes * sizeof(uint32_t)));
+                RT_HIP(w->wfHitNode.reserve(2 * nodes * sizeof(uint32_t))); // one per hit-queue entry
+                RT_HIP(w->wfGlossy.reserve(calls * sizeof(WfGlossy)));
+                P.wfRays = static_cast<WfRay*>(w->wfRays.ptr);
+                P.wfNodes = static_cast<WfNode*>(w->wfNodes.ptr);
+                P.wfMeta = static_cast<uint32_t*>(w->wfMeta.ptr);
+                P.wfValue = static_cast<float*>(w->wfValue.ptr);
+                P.wfHits = static_cast<uint32_t*>(w->wfHits.ptr);
+                P.wfHitNode = static_cast<uint32_t*>(w->wfHitNode.ptr);
+                P.wfGlossy = static_cast<WfGlossy*>(w->wfGlossy.ptr);
+                P.wfCapacity = uint32_t(nodes);
+                P.wfGlossyCapacity = uint32_t(calls);
+                if (cap < 2 * nodes) cap = 2 * nodes;
+            }
         }
-        RT_HIP(b->queue.reserve(cap * sizeof(HitEntry)));
-        RT_HIP(b->queueCounters.reserve(3 * Q_COUNT * sizeof(unsigned long long)));
-        RT_HIP(b->gaveUpQueue.reserve(cap * sizeof(uint32_t)));
-        const size_t items = cap * size_t(P.shadowSamplesPerHit > 0 ? P.shadowSamplesPerHit : 1);
-        if (items >= (size_t(1) << 32)) return fail(RT_ERR_LIMIT, "too many shadow samples per pass (pixels x samples x light samples must stay below 2^32)");
-        RT_HIP(b->visibility.reserve(items));
-        RT_HIP(b->shadowQueue.reserve(items * sizeof(uint32_t)));
-        P.shadowQueue = static_cast<uint32_t*>(b->shadowQueue.ptr);
+        const size_t items = cap * perHit;
+        if (items >= (size_t(1) << 32)) return fail(RT_ERR_LIMIT, "too many shadow samples per pass (pixels x light samples per hit must stay below 2^32)");
+        RT_HIP(w->queue.reserve(cap * sizeof(HitEntry)));
+        RT_HIP(w->queueCounters.reserve(3 * Q_COUNT * sizeof(unsigned long long)));
+        RT_HIP(w->gaveUpQueue.reserve(cap * sizeof(uint32_t)));
+        RT_HIP(w->visibility.reserve(items));
+        RT_HIP(w->shadowQueue.reserve(items * sizeof(uint32_t)));
+        P.shadowQueue = static_cast<uint32_t*>(w->shadowQueue.ptr);
         rt::size_pair_stack(P);
         if (P.pairSpillEntries > 0) {
-            RT_HIP(b->pairSpill.reserve(size_t(P.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
-            P.pairSpill = static_cast<uint32_t*>(b->pairSpill.ptr);
+            RT_HIP(w->pairSpill.reserve(size_t(P.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
+            P.pairSpill = static_cast<uint32_t*>(w->pairSpill.ptr);
         }
-        P.queue = static_cast<HitEntry*>(b->queue.ptr);
+        P.queue = static_cast<HitEntry*>(w->queue.ptr);
         // counter blocks: primary pass, lighting round A, lighting round B (one block serves all when the rounds are not split)
         static const int overlap = [] {
             const char* e = std::getenv("RT_OVERLAP"); // 0: the camera rays that gave up are finished before any lighting starts
             return e ? std::atoi(e) : 1;
         }();
-        P.primaryCounters = static_cast<unsigned long long*>(b->queueCounters.ptr);
+        P.primaryCounters = static_cast<unsigned long long*>(w->queueCounters.ptr);
         P.queueCounters = P.primaryCounters + (overlap ? Q_COUNT : 0);
-        P.gaveUpQueue = static_cast<uint32_t*>(b->gaveUpQueue.ptr);
+        P.gaveUpQueue = static_cast<uint32_t*>(w->gaveUpQueue.ptr);
         P.shadowQueueItems = uint32_t(items);
         if (overlap) {
-            aux.stream = b->auxStream;
-            aux.fork = b->evFork;
-            aux.join = b->evJoin;
+            aux.stream = w->auxStream;
+            aux.fork = w->evFork;
+            aux.join = w->evJoin;
+            aux.shadowMarks = stats ? w->evShadowB : nullptr;
             aux.counters = P.primaryCounters + 2 * Q_COUNT;
             aux.pairSpillWaves = 2048; // the second round is small
             if (P.pairSpillEntries > 0) {
-                RT_HIP(b->pairSpillAux.reserve(size_t(aux.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
-                aux.pairSpill = static_cast<uint32_t*>(b->pairSpillAux.ptr);
+                RT_HIP(w->pairSpillAux.reserve(size_t(aux.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
+                aux.pairSpill = static_cast<uint32_t*>(w->pairSpillAux.ptr);
             }
             useAux = true;
         }
-        P.visibility = static_cast<uint8_t*>(b->visibility.ptr);
+        P.visibility = static_cast<uint8_t*>(w->visibility.ptr);
         P.queueCapacity = cap;
     }
     float* dOut = outRgb;
     if (!devicePtr) {
-        RT_HIP(b->frame.reserve(nPix * 12));
-        dOut = static_cast<float*>(b->frame.ptr);
+        RT_HIP(w->frame.reserve(nPix * 12));
+        dOut = static_cast<float*>(w->frame.ptr);
     }
     P.out = dOut;
-    P.stats = static_cast<unsigned long long*>(b->stats.ptr);
+    RT_HIP(w->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
+    P.stats = static_cast<unsigned long long*>(w->stats.ptr);
     P.countTests = stats != nullptr && params->count_tests != 0;
-    RT_HIP(hipMemsetAsync(b->stats.ptr, 0, STAT_COUNT * sizeof(unsigned long long), s));
+    RT_HIP(hipMemsetAsync(w->stats.ptr, 0, STAT_COUNT * sizeof(unsigned long long), s));
     // a synchronous wait is only needed when the caller wants numbers or host pixels back
     const bool wait = stats != nullptr || !devicePtr;
-    if (stats) RT_HIP(hipEventRecord(b->evStart, s));
-    bool splitRecorded = false;
+    if (stats) RT_HIP(hipEventRecord(w->evStart, s));
+    bool splitRecorded = false, shadowMarksRecorded = false;
     unsigned long long wavefrontNodes = 0;
-    RT_HIP(launch_render(P, s, stats ? b->evMid : nullptr, stats ? b->evSplit : nullptr, &splitRecorded, &wavefrontNodes, useAux ? &aux : nullptr));
-    if (stats) RT_HIP(hipEventRecord(b->evStop, s));
+    {
+        const hipError_t e = launch_render(P, s, stats ? w->evMid : nullptr, stats ? w->evSplit : nullptr, &splitRecorded, &wavefrontNodes, useAux ? &aux : nullptr, &shadowMarksRecorded);
+        if (e == hipErrorOutOfMemory && P.wfNodes)
+            return fail(RT_ERR_LIMIT, "the call tree of a single pixel sample exceeds the node buffer of the wavefront passes (" + std::to_string(P.wfCapacity) +
+                                          " nodes): glossy_filter_size ^ ray_depth, with see-through continuations in between, is too large");
+        RT_HIP(e);
+    }
+    if (stats) RT_HIP(hipEventRecord(w->evStop, s));
     if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
-    if (wait) RT_HIP(hipStreamSynchronize(s));
+    if (wait) {
+        RT_HIP(hipStreamSynchronize(s));
+        lease.waited = true;
+    }
     if (stats) {
         unsigned long long h[STAT_COUNT];
-        RT_HIP(hipMemcpy(h, b->stats.ptr, sizeof h, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(h, w->stats.ptr, sizeof h, hipMemcpyDeviceToHost));
         stats->primary_rays = h[STAT_PRIMARY];
         stats->shadow_rays = h[STAT_SHADOW];
         stats->bounce_rays = h[STAT_BOUNCE];
@@ -830,8 +946,8 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         stats->box_tests = h[STAT_BOX];
         stats->triangle_tests = h[STAT_TRI];
         stats->transparency_overflows = h[STAT_OVERFLOW];
-        RT_HIP(hipEventElapsedTime(&stats->kernel_ms, b->evStart, b->evMid));
-        RT_HIP(hipEventElapsedTime(&stats->resolve_ms, b->evMid, b->evStop));
+        RT_HIP(hipEventElapsedTime(&stats->kernel_ms, w->evStart, w->evMid));
+        RT_HIP(hipEventElapsedTime(&stats->resolve_ms, w->evMid, w->evStop));
         stats->shadow_box_tests = h[STAT_SHADOW_BOX];
         stats->shadow_triangle_tests = h[STAT_SHADOW_TRI];
         stats->culled_shadow_rays = h[STAT_CULLED];
@@ -841,10 +957,11 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         stats->stream_prim_steps = h[STAT_STREAM_PRIM_STEPS];
         stats->stream_entries = h[STAT_STREAM_ENTRIES];
         if (splitRecorded) {
-            RT_HIP(hipEventElapsedTime(&stats->primary_ms, b->evStart, b->evSplit[0]));
-            RT_HIP(hipEventElapsedTime(&stats->cull_ms, b->evSplit[0], b->evSplit[1]));
-            RT_HIP(hipEventElapsedTime(&stats->shadow_ms, b->evSplit[1], b->evSplit[2]));
-            RT_HIP(hipEventElapsedTime(&stats->shade_ms, b->evSplit[2], b->evSplit[3]));
+            RT_HIP(hipEventElapsedTime(&stats->primary_ms, w->evStart, w->evSplit[0]));
+            RT_HIP(hipEventElapsedTime(&stats->cull_ms, w->evSplit[0], w->evSplit[1]));
+            RT_HIP(hipEventElapsedTime(&stats->shadow_ms, w->evSplit[1], w->evSplit[2]));
+            RT_HIP(hipEventElapsedTime(&stats->shade_ms, w->evSplit[2], w->evSplit[3]));
+            if (shadowMarksRecorded) RT_HIP(hipEventElapsedTime(&stats->shadow_b_ms, w->evShadowB[0], w->evShadowB[1]));
         }
     }
     return RT_OK;

@@ -21,12 +21,13 @@ enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TR
 struct SplitAux {
     hipStream_t stream;
     hipEvent_t fork, join;
+    hipEvent_t* shadowMarks; // null, or two events recorded on `stream` around the second round's shadow kernel
     unsigned long long* counters;
     uint32_t* pairSpill;
     uint32_t pairSpillWaves;
 };
 hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded,
-    unsigned long long* wavefrontNodes = nullptr, const SplitAux* aux = nullptr);
+    unsigned long long* wavefrontNodes = nullptr, const SplitAux* aux = nullptr, bool* shadowMarksRecorded = nullptr);
 
 // Shadow pass sizing: clamps P.pairStackLds to what the hierarchy can need and sets P.pairSpillEntries (per wave)
 // and P.pairSpillWaves (the most waves the pass is launched with); the caller provides P.pairSpill accordingly.

@@ -1484,10 +1484,12 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
         if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, st, P);
         else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), lds, st, P);
     };
-    auto lighting = [&](const FrameParams& R, hipStream_t st, hipEvent_t* marks) {
+    auto lighting = [&](const FrameParams& R, hipStream_t st, hipEvent_t* marks, hipEvent_t* shadowOnly = nullptr) {
         if (R.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, st, R);
         if (marks) (void)hipEventRecord(marks[1], st);
+        if (shadowOnly) (void)hipEventRecord(shadowOnly[0], st);
         if (R.shadowSamplesPerHit > 0) launch_stream<false>(R, gridDirect.x, streamLds, st);
+        if (shadowOnly) (void)hipEventRecord(shadowOnly[1], st);
         if (marks) (void)hipEventRecord(marks[2], st);
         hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, st, R);
         if (marks) (void)hipEventRecord(marks[3], st);
@@ -1514,7 +1516,7 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
     B.pairSpill = aux->pairSpill;
     B.pairSpillWaves = aux->pairSpillWaves;
     hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, aux->stream, B.queueCounters, (const unsigned long long*)&P.queueCounters[Q_RANGE_END], (const unsigned long long*)&P.primaryCounters[Q_HITS]);
-    lighting(B, aux->stream, nullptr);
+    lighting(B, aux->stream, nullptr, ev ? aux->shadowMarks : nullptr);
     if ((e = hipEventRecord(aux->join, aux->stream)) != hipSuccess) return e;
     lighting(P, stream, ev);
     if ((e = hipStreamWaitEvent(stream, aux->join, 0)) != hipSuccess) return e;
@@ -1661,9 +1663,10 @@ bool direct_only(const FrameParams& P)
 }
 
 hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* splitEvents, bool* splitRecorded,
-    unsigned long long* wavefrontNodes, const SplitAux* aux)
+    unsigned long long* wavefrontNodes, const SplitAux* aux, bool* shadowMarksRecorded)
 {
     if (splitRecorded) *splitRecorded = false;
+    if (shadowMarksRecorded) *shadowMarksRecorded = false;
     unsigned long long nodesEvaluated = 0;
     struct Report {
         unsigned long long* to;
@@ -1697,6 +1700,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
             const dim3 gridDirect(waves < 256u * 32u ? waves : 256u * 32u); // at most every wave slot of the chip
             hipEvent_t* ev = (splitEvents && sBegin == 0 && sEnd == P.samplesPerPixel) ? splitEvents : nullptr;
             if (ev && splitRecorded) *splitRecorded = true;
+            if (ev && aux && aux->shadowMarks && shadowMarksRecorded) *shadowMarksRecorded = true;
             return prune ? launch_split_t<true>(P, gridDirect, lds, stream, ev, aux) : launch_split_t<false>(P, gridDirect, lds, stream, ev, aux);
         }
         if (prune) return glossy ? launch_render_t<true, true>(P, lds, stream) : launch_render_t<true, false>(P, lds, stream);

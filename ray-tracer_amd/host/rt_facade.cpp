@@ -355,9 +355,20 @@ void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const st
     std::vector<std::vector<float>> parts { size_t(n) };
     std::vector<std::string> errors { size_t(n) };
     std::vector<std::thread> threads;
-    for (int i = 0; i < n; i++)
-        threads.emplace_back([&, i] {
-            if (!shares[size_t(i)].bvh || !shares[size_t(i)].bvh->handle()) return;
+    // (whatever happens below, every thread that was started is joined before this function is left)
+    struct Joiner {
+        std::vector<std::thread>& threads;
+        ~Joiner()
+        {
+            for (std::thread& t : threads)
+                if (t.joinable()) t.join();
+        }
+    } joiner { threads };
+    auto share_job = [&](int i) {
+            if (!shares[size_t(i)].bvh || !shares[size_t(i)].bvh->handle()) {
+                errors[size_t(i)] = "share " + std::to_string(i) + " has no hierarchy";
+                return;
+            }
             int rows = 0;
             for (int b = i; b < nBlocks; b += n) rows += std::min(res.y, (b + 1) * rowBlock) - b * rowBlock;
             parts[size_t(i)].assign(size_t(rows) * size_t(res.x) * 3, 0.0f);
@@ -366,7 +377,14 @@ void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const st
                 rt_render_blocks(shares[size_t(i)].bvh->handle(), &cam, lights.data(), int32_t(lights.size()), &f, &p, res.x, res.y, rowBlock, i, n,
                     parts[size_t(i)].data(), 0, nullptr, nullptr) != RT_OK)
                 errors[size_t(i)] = rt_last_error(); // (the error text belongs to the thread that made the call)
-        });
+    };
+    try {
+        for (int i = 0; i < n; i++) threads.emplace_back(share_job, i);
+    } catch (const std::exception& e) {
+        for (std::thread& t : threads) t.join();
+        std::fprintf(stderr, "renderRayTracingTiled: cannot start a thread per share: %s\n", e.what());
+        return;
+    }
     for (std::thread& t : threads) t.join();
     for (const std::string& e : errors)
         if (!e.empty()) {

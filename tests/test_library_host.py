@@ -38,7 +38,7 @@ def test_struct_sizes_match_header(lib):
     assert C.sizeof(capi.Light) == 22 * 4
     assert C.sizeof(capi.Camera) == 9 * 4
     assert C.sizeof(capi.MeshDesc) == 64
-    assert C.sizeof(capi.Stats) == 144  # 7 x u64 + 2 x f32, 2 x u64 + 4 x f32, 2 x u64, 4 x u64
+    assert C.sizeof(capi.Stats) == 152  # 7 x u64 + 2 x f32, 2 x u64 + 4 x f32, 2 x u64, 4 x u64, f32 + padding
     p = capi.Params()
     lib.lib.rt_default_params(C.byref(p))
     d = rt.default_params()
