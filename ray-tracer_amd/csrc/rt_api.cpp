@@ -956,6 +956,11 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         stats->stream_box_steps = h[STAT_STREAM_BOX_STEPS];
         stats->stream_prim_steps = h[STAT_STREAM_PRIM_STEPS];
         stats->stream_entries = h[STAT_STREAM_ENTRIES];
+        if (std::getenv("RT_DEBUG_STATS")) {
+            std::fprintf(stderr, "rt_render debug slots:");
+            for (int i = STAT_DEBUG0; i < STAT_DEBUG_END; i++) std::fprintf(stderr, " %llu", h[i]);
+            std::fprintf(stderr, "\n");
+        }
         if (splitRecorded) {
             RT_HIP(hipEventElapsedTime(&stats->primary_ms, w->evStart, w->evSplit[0]));
             RT_HIP(hipEventElapsedTime(&stats->cull_ms, w->evSplit[0], w->evSplit[1]));

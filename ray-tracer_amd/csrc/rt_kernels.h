@@ -7,7 +7,9 @@
 namespace rt {
 
 enum { STAT_PRIMARY = 0, STAT_SHADOW, STAT_BOUNCE, STAT_PROBE, STAT_BOX, STAT_TRI, STAT_OVERFLOW, STAT_SHADOW_BOX, STAT_SHADOW_TRI, STAT_CULLED,
-    STAT_STREAM_PACKETS, STAT_STREAM_BOX_STEPS, STAT_STREAM_PRIM_STEPS, STAT_STREAM_ENTRIES, STAT_COUNT };
+    STAT_STREAM_PACKETS, STAT_STREAM_BOX_STEPS, STAT_STREAM_PRIM_STEPS, STAT_STREAM_ENTRIES,
+    STAT_DEBUG0, STAT_DEBUG_END = STAT_DEBUG0 + 8, // slots for timing builds of a kernel (printed when RT_DEBUG_STATS is set)
+    STAT_COUNT = STAT_DEBUG_END };
 
 // Renders the P.rowsLocal local rows of the call: the traversal/shading passes, then (more than one sample per pixel)
 // the resolve pass.  `afterPasses`, when not null, is recorded between the two.  `split`, when not null, points

@@ -394,16 +394,13 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // never share a step.  A lane works for different rays every step; what it needs of them comes from a ray table in
 // LDS.  A ray that has been blocked gets a flag there, and its remaining pairs are dropped when popped.
 //
-// Ray groups (G = 1, 2 or 4).  The queries of a packet are consecutive work items, i.e. mostly light samples of the
+// Ray groups (G = 1 or 2).  The queries of a packet are consecutive work items, i.e. mostly light samples of the
 // same hit: rays with one origin and nearly one direction, which enter mostly the same nodes.  A stack entry is
 // therefore (group of G consecutive rays, node, which rays of the group have entered it): ONE popped entry, one
 // staged node record, and G box tests of that record, each ray deciding for itself exactly as it would alone (a ray
-// whose bit is clear is not tested and cannot enter a child).  The step's fixed cost (pop, record fetch through the
-// per-CU cache and LDS, compaction, pushes) is what the kernel is short of, vector arithmetic is not, so sharing
-// an entry among rays saves steps: on the headline frame 35.1 M box steps with G = 1, 24.7 M with G = 2 (1.46 of 2 rays
-// share an entry on average), 18.8 M with G = 4 (2.0 of 4).  The registers the extra rays take cost occupancy,
-// which this latency-bound kernel needs more: G = 2 held to 96 registers is the fastest (8.67 ms against 8.83 ms
-// for G = 1 and 10.7 ms for G = 4).
+// that has not entered the node cannot enter a child).  On the headline frame: 35.1 M box steps with G = 1, 24.8 M with
+// G = 2 (1.46 of 2 rays share an entry on average).  G = 2 is the faster by about 7 %; groups of four (18.8 M steps, 2.0
+// of 4 rays per entry) were slower than either and are no longer built.
 //
 // Stack bound.  The top k <= 64 entries are popped, the topmost by lane k-1, the one below it by lane k-2, and so
 // on; the children are pushed in lane order (those of lane 0 lowest).  By induction the tree levels of the
@@ -415,17 +412,55 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 // Persistent waves: a wave whose packet has ended takes the next one from a global cursor and stops once
 // the cursor has passed the packet count.
 constexpr int STREAM_RAYS = 64;                           // rays per packet
-// entry = group index (6, 5, 4 bits for G = 1, 2, 4) | entered-mask (G bits) | node index or primitive slot
-template <int G> struct StreamFormat {
-    static constexpr int LOG_G = G == 1 ? 0 : (G == 2 ? 1 : 2);
-    static constexpr int GROUP_BITS = 6 - LOG_G;
-    static constexpr int REF_BITS = 32 - GROUP_BITS - G; // 25, 25, 24
-    static constexpr uint32_t REF_MASK = (1u << REF_BITS) - 1u;
-    static constexpr uint32_t ALL = (1u << G) - 1u;
+__device__ __forceinline__ bool lane_in(unsigned long long mask);
+__host__ __device__ constexpr uint32_t stream_ref_limit(int group) { return group == 1 ? (1u << 25) - 1u : (1u << 24) - 1u; }
+
+// Stack / leaf-pool entries of the single-ray (G = 1) and the two-ray (G = 2) stream.  `ref` is a child reference as the
+// node record holds it: >= 0 an inner node's index, < 0 = ~(primitive slot of a leaf).
+//   G = 1:  (ref << 6) | ray
+//   G = 2:  code << 30 | (ref & 0xffffff) << 6 | group, group = ray / 2, code = which rays of the group have entered the
+//           node: 1 = the first only, 2 = both, 3 = the second only (so each "has entered" is ONE unsigned comparison)
+template <int G> struct PairEntry {
+    static __device__ __forceinline__ uint32_t root(int32_t ref, uint32_t group, uint32_t raysOfGroup /* bit per ray */)
+    {
+        if (G == 1) return (uint32_t(ref) << 6) | group;
+        const uint32_t code = raysOfGroup == 3u ? 2u : (raysOfGroup == 1u ? 1u : 3u);
+        return (code << 30) | ((uint32_t(ref) & 0xffffffu) << 6) | group;
+    }
+    // byte offset of the group's first ray in a table of 16-byte rows
+    static __device__ __forceinline__ uint32_t ray_bytes(uint32_t e) { return G == 1 ? (e << 4) & 0x3f0u : (e << 5) & 0x3e0u; }
+    static __device__ __forceinline__ uint32_t first_ray(uint32_t e) { return G == 1 ? e & 63u : (e & 31u) << 1; }
+    // byte offset of the 64-byte record of an inner node entry
+    static __device__ __forceinline__ uint32_t record_bytes(uint32_t e) { return G == 1 ? e & ~63u : e & 0x3fffffc0u; }
+    // primitive slot of a leaf entry
+    static __device__ __forceinline__ uint32_t slot(uint32_t e) { return G == 1 ? uint32_t(~(int32_t(e) >> 6)) : ~(e >> 6) & 0xffffffu; }
+    // lanes whose entry says that ray g of the group has entered the node
+    static __device__ __forceinline__ unsigned long long entered(uint32_t e, int g)
+    {
+        if (G == 1) return ~0ull;
+        return g == 0 ? __builtin_amdgcn_uicmp(e, 0xc0000000u, 36 /* < */) : __builtin_amdgcn_uicmp(e, 0x80000000u, 35 /* >= */);
+    }
+    static __device__ __forceinline__ uint32_t entered_bits(uint32_t e) { return G == 1 ? 1u : (e < 0xc0000000u ? 1u : 0u) | (e >= 0x80000000u ? 2u : 0u); }
+    // entry of the child `ref` for the rays that enter it (lane masks first / second; second = first for G = 1)
+    static __device__ __forceinline__ uint32_t child(uint32_t e, int32_t ref, unsigned long long first, unsigned long long second)
+    {
+        if (G == 1) return (uint32_t(ref) << 6) | (e & 63u);
+        uint32_t code = lane_in(second) ? 0xc0000000u : 0x40000000u;
+        code = lane_in(first & second) ? 0x80000000u : code;
+        // (code & top) | (rest & ~top) as one bit-field insert; the compiler would otherwise spend an AND and an OR on it
+        const uint32_t rest = (uint32_t(ref) << 6) | (e & 31u);
+        uint32_t entry;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(entry) : "s"(0xc0000000u), "v"(code), "v"(rest));
+        return entry;
+    }
 };
-__host__ __device__ constexpr uint32_t stream_ref_limit(int group) { return group == 4 ? (1u << 24) - 1u : (1u << 25) - 1u; }
 constexpr int STREAM_PER_LEVEL = 128;                     // stack entries per inner tree level
 constexpr int STREAM_LEAF_CAP = 192;                      // < 64 waiting + 128 from one step
+#ifndef RT_LEAF_TRIGGER
+#define RT_LEAF_TRIGGER 64
+#endif
+constexpr uint32_t STREAM_LEAF_TRIGGER = RT_LEAF_TRIGGER; // a primitive step runs once this many leaf entries wait (<= 64)
+
 constexpr uint32_t RAY_BLOCKED = 8u;                      // flag bit next to the three zero-direction bits
 
 constexpr int STREAM_STAGE_STRIDE = 1024 + 16;            // bytes between the four quarter-wave images of the record stage
@@ -493,9 +528,14 @@ __device__ __forceinline__ void lds_fence()
 // subtract and one packed multiply with the ray's origin component and reciprocal broadcast to both halves.
 // A ray that has been answered is poisoned in the ray table (origin x = +inf): its x slab products are both -inf or
 // both +inf, which fails `t_out <= 0` or `t_in > t_out`, so it enters nothing without any flag test here.
-__device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, float ox, float oy, float oz, float ix, float iy, float iz, bool& left, bool& right)
+// The answers are lane masks (one bit per lane, in scalar registers): the three rejections of each box are three vector
+// compares whose results are combined by scalar instructions, and the masks feed the prefix counts, the population
+// counts and the execution masks of the pushes directly, without a round trip through vector registers.
+// (compare codes of __builtin_amdgcn_fcmpf / sicmp: 10 = unordered or greater, 13 = unordered or less-or-equal,
+// 39 = signed greater-or-equal)
+__device__ __forceinline__ void boxes_entered_masks(f32x4 a, f32x4 b, f32x4 c, f32x4 o, f32x4 i, unsigned long long& left, unsigned long long& right)
 {
-    const f32x2 oX { ox, ox }, oY { oy, oy }, oZ { oz, oz }, iX { ix, ix }, iY { iy, iy }, iZ { iz, iz };
+    const f32x2 oX { o.x, o.x }, oY { o.y, o.y }, oZ { o.z, o.z }, iX { i.x, i.x }, iY { i.y, i.y }, iZ { i.z, i.z };
     const f32x2 p0 = (a.xy - oX) * iX; // left  x slab
     const f32x2 p1 = (a.zw - oY) * iY; // left  y slab
     const f32x2 p2 = (b.xy - oZ) * iZ; // left  z slab
@@ -506,9 +546,17 @@ __device__ __forceinline__ void boxes_entered(f32x4 a, f32x4 b, f32x4 c, float o
     const float toutL = fminf(fminf(fmaxf(p0.x, p0.y), fmaxf(p1.x, p1.y)), fmaxf(p2.x, p2.y));
     const float tinR = fmaxf(fmaxf(fminf(p3.x, p3.y), fminf(p4.x, p4.y)), fminf(p5.x, p5.y));
     const float toutR = fminf(fminf(fmaxf(p3.x, p3.y), fmaxf(p4.x, p4.y)), fmaxf(p5.x, p5.y));
-    left = !(tinL > toutL) && !(toutL <= 0) && !is_zero(tinL);
-    right = !(tinR > toutR) && !(toutR <= 0) && !is_zero(tinR);
+    // !(t_in > t_out) && !(t_out <= 0) && !(|t_in| <= 1e-6)
+    left = __builtin_amdgcn_fcmpf(tinL, toutL, 13) & __builtin_amdgcn_fcmpf(toutL, 0.0f, 10) & __builtin_amdgcn_fcmpf(fabsf(tinL), 0.000001f, 10);
+    right = __builtin_amdgcn_fcmpf(tinR, toutR, 13) & __builtin_amdgcn_fcmpf(toutR, 0.0f, 10) & __builtin_amdgcn_fcmpf(fabsf(tinR), 0.000001f, 10);
 }
+// number of set bits of `mask` below this lane, plus `base`
+__device__ __forceinline__ uint32_t mask_prefix(unsigned long long mask, uint32_t base)
+{
+    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), base));
+}
+// "this lane's bit of `mask` is set", as the execution mask of the branch (no vector instruction)
+__device__ __forceinline__ bool lane_in(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 
 // value of `v` in lane `src` (any lane may ask for any lane's value; all lanes must be active)
 __device__ __forceinline__ float lane_value(uint32_t src, float v)
@@ -516,13 +564,23 @@ __device__ __forceinline__ float lane_value(uint32_t src, float v)
     return __int_as_float(__builtin_amdgcn_ds_bpermute(int(src << 2), __float_as_int(v)));
 }
 
+// Timing build (-DRT_STREAM_TIMING): the shadow stream adds up, per wave, the clock ticks between marks inside its steps
+// and leaves the sums in the debug slots of the statistics block.
+#ifdef RT_STREAM_TIMING
+#define STREAM_MARK(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tick[i] += now_ - mark; mark = now_; } while (0)
+#else
+#define STREAM_MARK(i) do { } while (0)
+#endif
 template <bool COUNT, bool PRIMARY, int G>
-__global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FrameParams P)
+__global__ void __launch_bounds__(WAVE, 5) k_stream(const FrameParams P)
 {
+#ifdef RT_STREAM_TIMING
+    unsigned long long tick[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, mark = __builtin_amdgcn_s_memtime();
+#endif
     // Ray i of the packet is set up by lane i.  What a box step needs of it (origin, reciprocal direction, flags) goes
     // to a table in LDS; the direction, which only the rare primitive steps need, stays in lane i's registers and is
     // fetched from there with lane permutes.
-    using F = StreamFormat<G>;
+    using E = PairEntry<G>;
     extern __shared__ f32x4 streamLds[];
     char* stage = reinterpret_cast<char*>(streamLds);
     // Ray table: rayO[i] = (origin, flag word), rayI[i] = (reciprocal direction, unused).  A lane that works on a pair
@@ -555,6 +613,8 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
     const float tBound = PRIMARY ? FLT_MAX : 1.0f; // a shadow ray ends at the light sample (t = 1)
     const bool sceneBounded = S.bounded != 0;
     const uint32_t lastNode = S.numNodes > 0 ? uint32_t(S.numNodes - 1) : 0u, lastPrim = S.numPrims > 0 ? uint32_t(S.numPrims - 1) : 0u;
+    // (byte offset of the last node record, wave-uniform: what a staged fetch is clamped to)
+    const uint32_t lastNodeBytes = uint32_t(__builtin_amdgcn_readfirstlane(int(lastNode * uint32_t(sizeof(NodeRec)))));
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
@@ -614,112 +674,118 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
         rayO[lane] = f32x4 { r.o.x, r.o.y, r.o.z, __uint_as_float(zeroBits) };
         rayI[lane] = f32x4 { r.inv.x, r.inv.y, r.inv.z, 0.0f };
         const unsigned long long m = __builtin_amdgcn_ballot_w64(traced);
-        // The packet takes the general box test when some ray of it is outside the fast class of boxes_entered(): a
+        // The packet takes the general box test when some ray of it is outside the fast class of boxes_entered_masks(): a
         // direction component in the zero class or not finite, or an origin component beyond the bound (or NaN).
-        const bool zeroClass = !sceneBounded || __builtin_amdgcn_ballot_w64(traced && !r.fast) != 0;
+        // (passed through a scalar register so that the branches on it stay scalar branches)
+        const bool zeroClass = __builtin_amdgcn_readfirstlane(int(!sceneBounded || __builtin_amdgcn_ballot_w64(traced && !r.fast) != 0)) != 0;
         // one entry per group of G consecutive rays that has a ray past the root gate: (group, those rays, root)
         uint32_t count = 0, leafCount = 0;
         {
-            const uint32_t myGroup = uint32_t(lane) >> F::LOG_G;
-            const uint32_t groupMask = uint32_t(m >> (myGroup << F::LOG_G)) & F::ALL;
+            constexpr int LOG_G = G == 1 ? 0 : 1;
+            const uint32_t myGroup = uint32_t(lane) >> LOG_G;
+            const uint32_t groupMask = uint32_t(m >> (myGroup << LOG_G)) & ((1u << G) - 1u);
             const bool leader = (uint32_t(lane) & (uint32_t(G) - 1u)) == 0u && groupMask != 0u;
             const unsigned long long lm = __builtin_amdgcn_ballot_w64(leader);
             if (leader) {
                 const uint32_t at = lanes_below(lm);
-                const uint32_t head = (myGroup << (32 - F::GROUP_BITS)) | (groupMask << F::REF_BITS);
-                if (S.rootRef >= 0) pool.put(at, head | uint32_t(S.rootRef));
-                else leafPool[at] = head | uint32_t(~S.rootRef);
+                const uint32_t entry = E::root(S.rootRef, myGroup, groupMask);
+                if (S.rootRef >= 0) pool.put(at, entry);
+                else leafPool[at] = entry;
             }
             if (S.rootRef >= 0) count = uint32_t(__popcll(lm));
             else leafCount = uint32_t(__popcll(lm));
         }
         lds_fence();
+        STREAM_MARK(0); // packet set-up
         // ---- the stream
         while (count | leafCount) {
-            if (count && leafCount < 64u) {
-                // box step: the top 64 entries
+#ifdef RT_STREAM_TIMING
+            const bool wasBoxStep = count && leafCount < STREAM_LEAF_TRIGGER;
+#endif
+            if (count && leafCount < STREAM_LEAF_TRIGGER) {
+                // Box step of the single-ray and the two-ray stream, written for the fewest vector instructions per step:
+                // votes, prefix counts and push predicates live in scalar registers as lane masks; the entry formats
+                // (PairEntry) make the record's byte offset one AND and a child's entry two to four operations, the same
+                // for inner and leaf children.
                 const uint32_t k = count < 64u ? count : 64u;
                 if (COUNT) { nBoxSteps++; nEntries += k; }
-                const bool got = uint32_t(lane) < k;
-                const bool inLds = count - k + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
-                uint32_t e = 0u;
+                const unsigned long long got = k >= 64u ? ~0ull : (1ull << k) - 1ull;
                 count -= k;
-                if (inLds) {
-                    if (got) e = pool.lds[count + uint32_t(lane)];
-                } else {
-                    if (got) e = pool.get(count + uint32_t(lane));
-                }
+                const bool inLds = count + 128u <= pool.ldsEntries; // this step's pops and pushes stay clear of the spill
+                // (lanes without an entry read whatever lies above the top, possibly never written: the record offset is
+                // clamped below and their votes are masked out)
+                uint32_t e;
+                if (inLds) e = pool.lds[count + uint32_t(lane)];
+                else e = lane_in(got) ? pool.get(count + uint32_t(lane)) : 0u;
                 // the rays' values are read before the node loads are issued so that both are in flight together
-                // (an LDS-class operation placed after them would be made to wait for them)
-                const uint32_t first = (e >> (32 - F::GROUP_BITS)) << F::LOG_G; // first ray of the group
+                const char* const rayAt = reinterpret_cast<const char*>(rayO) + E::ray_bytes(e);
                 f32x4 ro[G], ri[G];
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    ro[g] = rayO[first + uint32_t(g)];
-                    ri[g] = rayI[first + uint32_t(g)];
+                    ro[g] = *reinterpret_cast<const f32x4*>(rayAt + g * 16);
+                    ri[g] = *reinterpret_cast<const f32x4*>(rayAt + STREAM_RAYS * 16 + g * 16);
                 }
                 asm volatile("" ::: "memory");
-                // (the index is clamped to the table: a fetch must stay inside it whatever an entry holds)
-                stage_records(S.nodes, min(e & F::REF_MASK, lastNode) * uint32_t(sizeof(NodeRec)), stageLds, quarter);
+                stage_records(S.nodes, min(E::record_bytes(e), lastNodeBytes), stageLds, quarter);
+                STREAM_MARK(1); // pop, ray reads and fetch issued
                 // the ray values are named as operands of the wait so that their LDS reads are issued ahead of it
                 if (G == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0])::"memory");
-                else if (G == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0])::"memory");
-                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0]), "+v"(ro[G > 2 ? 2 : 0]), "+v"(ri[G > 2 ? 2 : 0]), "+v"(ro[G > 3 ? 3 : 0]), "+v"(ri[G > 3 ? 3 : 0])::"memory");
-                // Straight-line from here: every lane evaluates the record its quad staged for it (lanes without an
-                // entry staged record 0 and have an empty ray mask).
+                else asm volatile("s_waitcnt vmcnt(0)" : "+v"(ro[0]), "+v"(ri[0]), "+v"(ro[G > 1 ? 1 : 0]), "+v"(ri[G > 1 ? 1 : 0])::"memory");
+                STREAM_MARK(2); // records arrived
                 const f32x4 a = staged[0], b = staged[1], c = staged[2];
                 const f32x2 refs = *reinterpret_cast<const f32x2*>(staged + 3);
                 const int32_t refL = __float_as_int(refs.x), refR = __float_as_int(refs.y);
-                // which rays of the group enter the left / right child: as bits of the entries to push, in place
-                uint32_t bitsL = 0u, bitsR = 0u;
-                bool anyL = false, anyR = false;
+                // per ray of the entry: has it entered the entry's node (always, for a single-ray entry), and which of the
+                // two child boxes does it enter
+                unsigned long long gL[G], gR[G];
 #pragma unroll
                 for (int g = 0; g < G; g++) {
-                    const bool in = (e >> (F::REF_BITS + g)) & 1u; // (e = 0 in the lanes without an entry)
-                    bool vL, vR;
+                    const unsigned long long in = E::entered(e, g) & got;
+                    unsigned long long mL, mR;
                     if (!zeroClass) {
-                        boxes_entered(a, b, c, ro[g].x, ro[g].y, ro[g].z, ri[g].x, ri[g].y, ri[g].z, vL, vR);
-                        if (COUNT && in && !(__float_as_uint(ro[g].w) & RAY_BLOCKED)) cnt.box += 2;
+                        boxes_entered_masks(a, b, c, ro[g], ri[g], mL, mR);
+                        if (COUNT && lane_in(in) && !(__float_as_uint(ro[g].w) & RAY_BLOCKED)) cnt.box += 2;
                     } else {
                         const uint32_t flags = __float_as_uint(ro[g].w);
-                        const bool live = in && !(flags & RAY_BLOCKED);
+                        const bool live = lane_in(in) && !(flags & RAY_BLOCKED);
                         if (COUNT && live) cnt.box += 2;
                         RayD q;
                         q.o = make3(ro[g].x, ro[g].y, ro[g].z);
                         q.inv = make3(ri[g].x, ri[g].y, ri[g].z);
                         q.zx = flags & 1u; q.zy = flags & 2u; q.zz = flags & 4u;
                         float tL, tR;
-                        vL = live && box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX;
-                        vR = live && box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX;
+                        mL = __builtin_amdgcn_ballot_w64(live && box_entry(q, a.x, a.z, b.x, a.y, a.w, b.y, tL) && tL < FLT_MAX);
+                        mR = __builtin_amdgcn_ballot_w64(live && box_entry(q, b.z, c.x, c.z, b.w, c.y, c.w, tR) && tR < FLT_MAX);
                     }
-                    const bool gL = vL && in, gR = vR && in;
-                    anyL = anyL || gL;
-                    anyR = anyR || gR;
-                    bitsL |= gL ? (1u << (F::REF_BITS + g)) : 0u;
-                    bitsR |= gR ? (1u << (F::REF_BITS + g)) : 0u;
+                    gL[g] = mL & in;
+                    gR[g] = mR & in;
                 }
-                const uint32_t tag = e & ~((1u << (32 - F::GROUP_BITS)) - 1u); // the group index, in place
-                // children that are inner nodes (reference >= 0) go back on the stack, those of higher lanes higher
-                const bool iL = anyL && refL >= 0, iR = anyR && refR >= 0;
-                const unsigned long long bL = __builtin_amdgcn_ballot_w64(iL), bR = __builtin_amdgcn_ballot_w64(iR);
-                const uint32_t nL = uint32_t(__popcll(bL)), nR = uint32_t(__popcll(bR));
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi(uint32_t(bR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bR),
-                    __builtin_amdgcn_mbcnt_hi(uint32_t(bL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bL), count))));
+                const unsigned long long anyL = G == 1 ? gL[0] : gL[0] | gL[G - 1], anyR = G == 1 ? gR[0] : gR[0] | gR[G - 1];
+                const unsigned long long innerL = __builtin_amdgcn_sicmp(refL, 0, 39), innerR = __builtin_amdgcn_sicmp(refR, 0, 39);
+                uint32_t entryL = E::child(e, refL, gL[0], gL[G - 1]), entryR = E::child(e, refR, gR[0], gR[G - 1]);
+                // children that are inner nodes go back on the stack, those of higher lanes higher (left below right)
+                const unsigned long long iL = anyL & innerL, iR = anyR & innerR;
+                const uint32_t at = mask_prefix(iR, mask_prefix(iL, 0u));
+#ifdef RT_STREAM_TIMING
+                asm volatile("" : "+v"(entryL), "+v"(entryR));
+#endif
+                STREAM_MARK(3); // stage read back, box tests, entries
                 if (inLds) {
-                    if (iL) pool.lds[at] = tag | bitsL | uint32_t(refL);
-                    if (iR) pool.lds[at + (iL ? 1u : 0u)] = tag | bitsR | uint32_t(refR);
+                    uint32_t* const top = pool.lds + count;
+                    if (lane_in(iL)) top[at] = entryL;
+                    if (lane_in(iR & iL)) top[at + 1u] = entryR;
+                    if (lane_in(iR & ~iL)) top[at] = entryR;
                 } else {
-                    if (iL) pool.put(at, tag | bitsL | uint32_t(refL));
-                    if (iR) pool.put(at + (iL ? 1u : 0u), tag | bitsR | uint32_t(refR));
+                    if (lane_in(iL)) pool.put(count + at, entryL);
+                    if (lane_in(iR)) pool.put(count + at + (lane_in(iL) ? 1u : 0u), entryR);
                 }
-                count += nL + nR;
-                // children that are leaves (reference = ~slot): to the primitive pool
-                const bool lL = anyL && refL < 0, lR = anyR && refR < 0;
-                const unsigned long long bLL = __builtin_amdgcn_ballot_w64(lL), bLR = __builtin_amdgcn_ballot_w64(lR);
-                if (lL) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLL >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLL), leafCount))] = tag | bitsL | uint32_t(~refL);
-                leafCount += uint32_t(__popcll(bLL));
-                if (lR) leafPool[__builtin_amdgcn_mbcnt_hi(uint32_t(bLR >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(bLR), leafCount))] = tag | bitsR | uint32_t(~refR);
-                leafCount += uint32_t(__popcll(bLR));
+                count += uint32_t(__popcll(iL)) + uint32_t(__popcll(iR));
+                // children that are leaves: to the primitive pool (any order), the left ones first
+                const unsigned long long lL = anyL & ~innerL, lR = anyR & ~innerR;
+                const uint32_t nLL = uint32_t(__popcll(lL));
+                if (lane_in(lL)) (leafPool + leafCount)[mask_prefix(lL, 0u)] = entryL;
+                if (lane_in(lR)) (leafPool + leafCount + nLL)[mask_prefix(lR, 0u)] = entryR;
+                leafCount += nLL + uint32_t(__popcll(lR));
             } else {
                 // primitive step: up to 64 (group, leaf) entries
                 const uint32_t k = leafCount < 64u ? leafCount : 64u;
@@ -727,10 +793,12 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 const bool got = uint32_t(lane) < k;
                 const uint32_t e = got ? leafPool[leafCount - 1u - uint32_t(lane)] : 0u;
                 leafCount -= k;
-                const uint32_t first = (e >> (32 - F::GROUP_BITS)) << F::LOG_G;
-                const uint32_t mask = got ? (e >> F::REF_BITS) & F::ALL : 0u;
+                // (single-ray entries hold the leaf's reference as the node record does: ~slot)
+                const uint32_t first = E::first_ray(e);
+                const uint32_t mask = got ? E::entered_bits(e) : 0u;
+                const uint32_t firstSlot = E::slot(e);
                 asm volatile("" ::: "memory");
-                stage_records(S.prims, min(e & F::REF_MASK, lastPrim) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
+                stage_records(S.prims, min(firstSlot, lastPrim) * uint32_t(sizeof(PrimRec)), stageLds, quarter);
                 stage_wait();
                 // The rays of the group one after the other, as a loop that is NOT unrolled: one copy of the triangle test
                 // in the code, and only one ray's values in registers at a time.
@@ -743,7 +811,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                     q.d = make3(lane_value(ray, r.d.x), lane_value(ray, r.d.y), lane_value(ray, r.d.z));
                     bool live = ((mask >> g) & 1u) && !(__float_as_uint(o.w) & RAY_BLOCKED);
                     if (live) {
-                        int32_t slot = int32_t(e & F::REF_MASK);
+                        int32_t slot = int32_t(firstSlot);
                         int32_t more;
                         bool firstRec = true;
                         do {
@@ -762,7 +830,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                             if (COUNT) cnt.tri++;
                             float t;
                             if (triangle_hit(q, p, tBound, t)) {
-                                // answered: flagged, and poisoned for the fast box test (see boxes_entered)
+                                // answered: flagged, and poisoned for the fast box test (see boxes_entered_masks)
                                 atomicOr(flag_word(ray), RAY_BLOCKED);
                                 *reinterpret_cast<float*>(rayO + ray) = __builtin_inff();
                                 live = false;
@@ -773,6 +841,7 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
                 }
             }
             __syncthreads(); // one wave per block: orders this step's LDS and spill traffic before the next step's
+            STREAM_MARK(wasBoxStep ? 4 : 5); // pushes + wait / the whole primitive step
         }
         // ---- answers
         const bool found = *flag_word(uint32_t(lane)) & RAY_BLOCKED;
@@ -806,7 +875,12 @@ __global__ void __launch_bounds__(WAVE, G == 4 ? 4 : 5) k_stream(const FramePara
             }
         }
         lds_fence();
+        STREAM_MARK(6); // answers
     }
+#ifdef RT_STREAM_TIMING
+    if (!PRIMARY && G <= 2 && P.stats && lane == 0)
+        for (int i = 0; i < 7; i++) atomicAdd(&P.stats[STAT_DEBUG0 + i], tick[i]);
+#endif
     flush_counts(cnt, P.stats, !PRIMARY);
     if (COUNT && !PRIMARY && P.stats && lane == 0) {
         atomicAdd(&P.stats[STAT_STREAM_PACKETS], (unsigned long long)nPacketsDone);
@@ -1433,12 +1507,10 @@ void launch_stream(const FrameParams& P, uint32_t wanted, size_t lds, hipStream_
     // camera rays that gave up are unrelated rays: no groups there
     const int group = PRIMARY ? 1 : P.streamGroup;
     if (P.countTests) {
-        if (group == 4) launch_stream_g<true, PRIMARY, PRIMARY ? 1 : 4>(P, wanted, lds, stream);
-        else if (group == 2) launch_stream_g<true, PRIMARY, PRIMARY ? 1 : 2>(P, wanted, lds, stream);
+        if (group == 2) launch_stream_g<true, PRIMARY, PRIMARY ? 1 : 2>(P, wanted, lds, stream);
         else launch_stream_g<true, PRIMARY, 1>(P, wanted, lds, stream);
     } else {
-        if (group == 4) launch_stream_g<false, PRIMARY, PRIMARY ? 1 : 4>(P, wanted, lds, stream);
-        else if (group == 2) launch_stream_g<false, PRIMARY, PRIMARY ? 1 : 2>(P, wanted, lds, stream);
+        if (group == 2) launch_stream_g<false, PRIMARY, PRIMARY ? 1 : 2>(P, wanted, lds, stream);
         else launch_stream_g<false, PRIMARY, 1>(P, wanted, lds, stream);
     }
 }
@@ -1681,8 +1753,8 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     const bool prune = !P.f.recursive && !P.f.transparency;
     const bool glossy = P.f.glossy != 0;
     // the shadow pass packs a node index or primitive slot into STREAM_REF_BITS bits (inner nodes are fewer than primitives)
-    if (P.streamGroup != 1 && P.streamGroup != 2 && P.streamGroup != 4) P.streamGroup = 2;
-    if (P.streamGroup == 4 && uint32_t(P.scene.numPrims) > stream_ref_limit(4)) P.streamGroup = 2;
+    if (P.streamGroup != 1 && P.streamGroup != 2) P.streamGroup = 2;
+    if (P.streamGroup != 1 && uint32_t(P.scene.numPrims) > stream_ref_limit(P.streamGroup)) P.streamGroup = 1; // (entries of groups have fewer reference bits)
     const bool fits = uint32_t(P.scene.numPrims) <= stream_ref_limit(P.streamGroup) && P.scene.stackDepth < 64;
     const bool split = P.queue != nullptr && P.f.accel_structure && !P.scene.hasSpheres && direct_only(P) && fits;
     // bounce features as wavefront passes
