@@ -31,12 +31,17 @@ l1acc = grab("tcc", "TCP_TOTAL_CACHE_ACCESSES_sum")
 thread_cycles, active_valu = grab("sq2", "SQ_THREAD_CYCLES_VALU"), grab("sq1", "SQ_ACTIVE_INST_VALU")
 insts_valu, insts_salu, insts_lds = grab("sq1", "SQ_INSTS_VALU"), grab("sq2", "SQ_INSTS_SALU"), grab("sq2", "SQ_INSTS_LDS")
 lds_conflict, lds_active = grab("sq2", "SQ_LDS_BANK_CONFLICT"), grab("sq2", "SQ_ACTIVE_INST_LDS")
+busy_cycles = grab("sq1", "SQ_BUSY_CYCLES")
+SHADER_ENGINES, SIMDS = 32, 1024  # SQ_BUSY_CYCLES is summed over the chip's 32 shader engines; 256 CUs x 4 SIMDs
 for k in per_kernel:
     if k in l2req:
         per_kernel[k]["l2_read_requests_per_launch"] = l2req[k]
         per_kernel[k]["l1_accesses_per_launch"] = l1acc.get(k)
     if k in thread_cycles and active_valu.get(k):
         per_kernel[k]["active_lane_frac"] = thread_cycles[k] / (64.0 * active_valu[k])
+    if k in insts_valu and busy_cycles.get(k):
+        # share of the chip's vector issue slots the launch uses: a wave64 vector instruction occupies its SIMD for 4 cycles
+        per_kernel[k]["valu_issue_util"] = insts_valu[k] * 4.0 / (SIMDS * busy_cycles[k] / SHADER_ENGINES)
     for name, table in (("valu_insts_per_launch", insts_valu), ("salu_insts_per_launch", insts_salu), ("lds_insts_per_launch", insts_lds),
                         ("lds_bank_conflict_cycles", lds_conflict), ("lds_active_cycles", lds_active)):
         if k in table:
@@ -46,7 +51,8 @@ doc = {
     "source": "profiles/%s/summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, of `python3 bench.py "
               "--steps 3 --warmup 1 --no-cpu-baseline` on one MI355X; per-dispatch averages" % tag,
     "counters": "l2_read_requests = TCP_TCC_READ_REQ_sum (requests of 64 or 128 bytes); active_lane_frac = "
-                "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); instruction counts are wave instructions",
+                "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); instruction counts are wave instructions; valu_issue_util = "
+                "SQ_INSTS_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32 shader engines)",
     "units": "FETCH_SIZE and WRITE_SIZE are reported in KiB; bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts 128-byte read "
              "requests as 64 bytes) + WRITE_SIZE x 1024",
     "per_kernel": per_kernel,

@@ -73,6 +73,28 @@ hipError_t upload(DevBuf& buf, const std::vector<T>& v)
 
 } // namespace
 
+// Share of the scene's triangle area that belongs to specular materials (ks != 0): how much of what a camera ray can
+// hit spawns reflection rays.
+float specular_area_share(const HostScene& scene)
+{
+    double total = 0.0, specular = 0.0;
+    for (const HostMesh& m : scene.meshes) {
+        double area = 0.0;
+        for (size_t t = 0; t + 2 < m.triangles.size(); t += 3) {
+            const float* a = &m.vertices[size_t(m.triangles[t]) * 8];
+            const float* b = &m.vertices[size_t(m.triangles[t + 1]) * 8];
+            const float* c = &m.vertices[size_t(m.triangles[t + 2]) * 8];
+            const double u[3] = { double(b[0]) - a[0], double(b[1]) - a[1], double(b[2]) - a[2] };
+            const double v[3] = { double(c[0]) - a[0], double(c[1]) - a[1], double(c[2]) - a[2] };
+            const double n[3] = { u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0] };
+            area += 0.5 * std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        }
+        total += area;
+        if (m.material.ks[0] != 0.0f || m.material.ks[1] != 0.0f || m.material.ks[2] != 0.0f) specular += area;
+    }
+    return total > 0.0 ? float(specular / total) : 0.0f;
+}
+
 struct rt_scene {
     HostScene host;
     // device copies are made on first use (so that building and inspecting a hierarchy needs no GPU)
@@ -81,6 +103,7 @@ struct rt_scene {
     int device = 0;
     DevBuf mats, texels, textures;
     ImageRec skybox[6] = {};
+    float specularShare = 0.0f; // specular_area_share() of the scene
 };
 
 // Device memory, events and the second stream one rt_render call works with.  A call takes a set from its hierarchy's
@@ -464,6 +487,7 @@ rt_status rt_scene_create(const rt_scene_desc* desc, rt_scene** out)
         delete s;
         return fail(RT_ERR_LIMIT, "rt_scene_create: unknown failure");
     }
+    s->specularShare = specular_area_share(s->host);
     *out = s;
     return RT_OK;
 }
@@ -827,15 +851,23 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             return e ? std::atol(e) : 0L;
         }();
         const bool bounce = features->recursive || features->glossy || features->transparency || (features->environment_mapping && params->enabled_refl_map);
-        if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && features->glossy))) {
+        // Which glossy frames gain from the wavefront passes (measured, 1920x1080, 36 spp, 64 samples per glossy call): where
+        // lighting casts shadow rays, or most surfaces are specular, the per-lane kernel loses (a lane traces a call's
+        // samples and their shadow rays one after the other: the dragon-class mesh under the area light took 170 s and
+        // more per quarter-size frame, 21 s in passes); where a fifth of the area is specular and no light casts shadows
+        // (Config 4: TransparentCornell 16.2 ms in passes, 14.9 ms per lane; TransparentCubes 9.8 / 9.0) it wins.
+        const bool glossyInPasses = features->glossy && (P.shadowSamplesPerHit > 0 || b->scene->specularShare > 0.5f);
+        if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && glossyInPasses))) {
             // at most 24 Mi nodes (2 GB of node records), and no more than the hit queue may hold entries for: a chunk has
             // at most `nodes` roots and `nodes` nodes, each with at most one hit entry
             size_t nodeLimit = size_t(24) << 20;
             if (nodeLimit > itemBudget / perHit / 2) nodeLimit = itemBudget / perHit / 2;
             size_t nodes = 4 * want;
             if (nodes < (size_t(1) << 20)) nodes = size_t(1) << 20;
-            // the largest call tree one pixel sample can have (filter^depth glossy samples at the deepest level; see-through
-            // continuations between the glossy levels add a few each): a chunk of a single sample must fit twice over
+            // room for the largest call tree one pixel sample can have (filter^depth glossy samples at the deepest level;
+            // see-through continuations between the glossy levels add a few each), twice over, if the limit allows: a
+            // chunk of a single sample then always fits.  Where it does not and a sample's tree really grows beyond the
+            // buffer, the pass is handed to the per-lane kernel (launch_render).
             size_t worst = 1, level = 1;
             if (features->glossy)
                 for (int d = 0; d < params->ray_depth && worst <= nodeLimit; d++) {
@@ -843,31 +875,26 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
                     worst += level;
                 }
             if (nodes < 2 * worst) nodes = 2 * worst;
-            // A frame whose single-sample tree does not fit the limit is rendered by the per-lane kernel (no node buffer
-            // is set up), which needs no memory per call; the two evaluation orders give the same frame.
-            const bool fitsLimit = 2 * worst <= nodeLimit;
             if (nodes > nodeLimit) nodes = nodeLimit;
             if (forcedNodes > 0) nodes = size_t(forcedNodes < 256 ? 256 : forcedNodes);
-            if (fitsLimit || forcedNodes > 0) {
-                const size_t calls = nodes / size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1) + 64;
-                RT_HIP(w->wfRays.reserve(nodes * sizeof(WfRay)));
-                RT_HIP(w->wfNodes.reserve(nodes * sizeof(WfNode)));
-                RT_HIP(w->wfMeta.reserve(nodes * sizeof(uint32_t)));
-                RT_HIP(w->wfValue.reserve(nodes * 12));
-                RT_HIP(w->wfHits.reserve(nodes * sizeof(uint32_t)));
-                RT_HIP(w->wfHitNode.reserve(2 * nodes * sizeof(uint32_t))); // one per hit-queue entry
-                RT_HIP(w->wfGlossy.reserve(calls * sizeof(WfGlossy)));
-                P.wfRays = static_cast<WfRay*>(w->wfRays.ptr);
-                P.wfNodes = static_cast<WfNode*>(w->wfNodes.ptr);
-                P.wfMeta = static_cast<uint32_t*>(w->wfMeta.ptr);
-                P.wfValue = static_cast<float*>(w->wfValue.ptr);
-                P.wfHits = static_cast<uint32_t*>(w->wfHits.ptr);
-                P.wfHitNode = static_cast<uint32_t*>(w->wfHitNode.ptr);
-                P.wfGlossy = static_cast<WfGlossy*>(w->wfGlossy.ptr);
-                P.wfCapacity = uint32_t(nodes);
-                P.wfGlossyCapacity = uint32_t(calls);
-                if (cap < 2 * nodes) cap = 2 * nodes;
-            }
+            const size_t calls = nodes / size_t(params->glossy_filter_size > 0 ? params->glossy_filter_size : 1) + 64;
+            RT_HIP(w->wfRays.reserve(nodes * sizeof(WfRay)));
+            RT_HIP(w->wfNodes.reserve(nodes * sizeof(WfNode)));
+            RT_HIP(w->wfMeta.reserve(nodes * sizeof(uint32_t)));
+            RT_HIP(w->wfValue.reserve(nodes * 12));
+            RT_HIP(w->wfHits.reserve(nodes * sizeof(uint32_t)));
+            RT_HIP(w->wfHitNode.reserve(2 * nodes * sizeof(uint32_t))); // one per hit-queue entry
+            RT_HIP(w->wfGlossy.reserve(calls * sizeof(WfGlossy)));
+            P.wfRays = static_cast<WfRay*>(w->wfRays.ptr);
+            P.wfNodes = static_cast<WfNode*>(w->wfNodes.ptr);
+            P.wfMeta = static_cast<uint32_t*>(w->wfMeta.ptr);
+            P.wfValue = static_cast<float*>(w->wfValue.ptr);
+            P.wfHits = static_cast<uint32_t*>(w->wfHits.ptr);
+            P.wfHitNode = static_cast<uint32_t*>(w->wfHitNode.ptr);
+            P.wfGlossy = static_cast<WfGlossy*>(w->wfGlossy.ptr);
+            P.wfCapacity = uint32_t(nodes);
+            P.wfGlossyCapacity = uint32_t(calls);
+            if (cap < 2 * nodes) cap = 2 * nodes;
         }
         const size_t items = cap * perHit;
         if (items >= (size_t(1) << 32)) return fail(RT_ERR_LIMIT, "too many shadow samples per pass (pixels x light samples per hit must stay below 2^32)");
@@ -923,13 +950,7 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     if (stats) RT_HIP(hipEventRecord(w->evStart, s));
     bool splitRecorded = false, shadowMarksRecorded = false;
     unsigned long long wavefrontNodes = 0;
-    {
-        const hipError_t e = launch_render(P, s, stats ? w->evMid : nullptr, stats ? w->evSplit : nullptr, &splitRecorded, &wavefrontNodes, useAux ? &aux : nullptr, &shadowMarksRecorded);
-        if (e == hipErrorOutOfMemory && P.wfNodes)
-            return fail(RT_ERR_LIMIT, "the call tree of a single pixel sample exceeds the node buffer of the wavefront passes (" + std::to_string(P.wfCapacity) +
-                                          " nodes): glossy_filter_size ^ ray_depth, with see-through continuations in between, is too large");
-        RT_HIP(e);
-    }
+    RT_HIP(launch_render(P, s, stats ? w->evMid : nullptr, stats ? w->evSplit : nullptr, &splitRecorded, &wavefrontNodes, useAux ? &aux : nullptr, &shadowMarksRecorded));
     if (stats) RT_HIP(hipEventRecord(w->evStop, s));
     if (!devicePtr) RT_HIP(hipMemcpyAsync(outRgb, dOut, nPix * 12, hipMemcpyDeviceToHost, s));
     if (wait) {

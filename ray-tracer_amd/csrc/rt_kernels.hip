@@ -1760,8 +1760,28 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     // bounce features as wavefront passes
     const bool wavefront = P.wfNodes != nullptr && P.f.accel_structure && !P.scene.hasSpheres && !direct_only(P) && fits;
     hipError_t e;
+    bool wavefrontGaveUp = false;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
-        if (wavefront) return prune ? wavefront_pass<true>(P, sBegin, sEnd, lds, stream, nodesEvaluated) : wavefront_pass<false>(P, sBegin, sEnd, lds, stream, nodesEvaluated);
+        if (wavefront && !wavefrontGaveUp) {
+            // (the ray counters as they stand, in case the pass has to be done again)
+            unsigned long long before[STAT_COUNT];
+            if (P.stats) {
+                if ((e = hipMemcpyAsync(before, P.stats, sizeof before, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            }
+            const unsigned long long nodesBefore = nodesEvaluated;
+            e = prune ? wavefront_pass<true>(P, sBegin, sEnd, lds, stream, nodesEvaluated) : wavefront_pass<false>(P, sBegin, sEnd, lds, stream, nodesEvaluated);
+            if (e != hipErrorOutOfMemory) return e;
+            // The call tree of a single pixel sample does not fit the node buffer (glossy_filter_size ^ ray_depth nodes at
+            // worst): this pass, and what is left of the frame, goes to the per-lane kernel, which needs no memory per
+            // call and gives the same frame.  What the abandoned pass has written is written again.
+            wavefrontGaveUp = true;
+            nodesEvaluated = nodesBefore;
+            if (P.stats) {
+                if ((e = hipMemcpyAsync(P.stats, before, sizeof before, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+                if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            }
+        }
         P.sampleBegin = sBegin;
         P.sampleEnd = sEnd;
         P.logicalBlocks = tiles * uint32_t(sEnd - sBegin);

@@ -404,21 +404,31 @@ def test_wavefront_chunks_that_overflow_are_split():
 
 
 def test_wavefront_nodes_are_reported(lib):
-    """rt_stats.wavefront_nodes says which way a frame went: a glossy frame goes through the wavefront passes unless they
-    are switched off, a direct-lighting frame never does."""
+    """rt_stats.wavefront_nodes says which way a frame went.  Left to itself the library sends a glossy frame through the
+    wavefront passes when a light casts shadow rays or most of the scene's area is specular, and to the per-lane kernel
+    otherwise; a direct-lighting frame never takes the passes, a mirror frame only when forced."""
     g, sc, orc, sh, bvh = setup(lib, "transparent_cornell")
     lights, n = sc.light_array()
     W, H = 64, 40
-    _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, glossy=1, transparency=1), rt.default_params(glossy_filter_size=16), W, H)
-    if os.environ.get("RT_WAVEFRONT") == "0":
+    forced = os.environ.get("RT_WAVEFRONT")
+    _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, glossy=1, transparency=1, hard_shadow=1), rt.default_params(glossy_filter_size=16), W, H)
+    if forced == "0":
         assert st.wavefront_nodes == 0
     else:
         assert st.wavefront_nodes >= W * H and st.bounce_rays > 0
+    # no shadow rays and a fifth of the area specular: per lane unless forced
+    _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, glossy=1, transparency=1), rt.default_params(glossy_filter_size=16), W, H)
+    assert (st.wavefront_nodes > 0) == (forced == "1")
+    # everything specular (the monkey): passes unless switched off
+    g2, sc2, orc2, sh2, bvh2 = setup(lib, "monkey")
+    lights2, n2 = sc2.light_array()
+    _, st = lib.render(bvh2, cam("A", (W, H)), lights2, n2, rt.features(shading=1, glossy=1), rt.default_params(glossy_filter_size=4, ray_depth=2), W, H)
+    assert (st.wavefront_nodes > 0) == (forced != "0")
     _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, hard_shadow=1), rt.default_params(), W, H)
     assert st.wavefront_nodes == 0
     # mirror recursion: wavefront only when forced
     _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, recursive=1), rt.default_params(), W, H)
-    assert (st.wavefront_nodes > 0) == (os.environ.get("RT_WAVEFRONT") == "1")
+    assert (st.wavefront_nodes > 0) == (forced == "1")
 
 
 def test_headline_frame_at_full_size(lib):
