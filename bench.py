@@ -32,7 +32,12 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 1920, 1080
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
-FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak
+FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak (packed fused multiply-add in every lane)
+FP32_NO_FMA_TFLOPS = 78.6  # the same without fused multiply-add: this path is compiled -ffp-contract=off by contract
+# The compiled reference as it is against the oracle, one thread each, on THIS benchmark's mesh (81,920 triangles, same
+# light, shading + soft shadows, 16 spp, 48x27 pixels = 75,200 rays): 101.3 s against 0.340 s, measured in the build
+# container (8-vCPU Xeon VM, g++ 11.4) by tools/time_reference_headline.py; BASELINE.md section 4 has the table.
+REFERENCE_AS_IS_RATIO = 298.0
 L2_PEAK_GBS = 34500.0      # MI355X aggregate L2 bandwidth (8 XCDs)
 CPU_ROW_STEP = 12          # the CPU leg renders every 12th row of the frame
 # the kernels of one frame of the headline workload as rocprofv3 names them (timed variants: test counting off)
@@ -158,11 +163,12 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, shadow_ms, primary_ms, shade_ms, cull_ms, rays, traced = 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0
+    kernel_ms, shadow_ms, shadow_b_ms, primary_ms, shade_ms, cull_ms, rays, traced = 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0, 0
     for _ in range(args.steps):
         st = step()
         kernel_ms += st.kernel_ms
         shadow_ms += st.shadow_ms
+        shadow_b_ms += st.shadow_b_ms
         primary_ms += st.primary_ms
         shade_ms += st.shade_ms
         cull_ms += st.cull_ms
@@ -185,7 +191,11 @@ def main():
     my_pixels = WIDTH * sum(tiling.block_rows(b, HEIGHT)[1] - tiling.block_rows(b, HEIGHT)[0] for b in my_blocks)
     have_split = shadow_ms > 0.0
     avg_kernel_s = kernel_ms / args.steps / 1e3
-    dom_s = (shadow_ms if have_split else kernel_ms) / args.steps / 1e3
+    # The shadow queries of a frame are answered by two launches: the main round (k_stream<false, false, 2>) and, on the
+    # library's second stream beside it, the small round for the hits of the camera rays that were finished late
+    # (k_stream<false, false, 1>).  The test counts below cover both, so the time does too: the SUM of the two launches'
+    # durations, although they overlap (the second one's includes its wait for wave slots): a conservative denominator.
+    dom_s = ((shadow_ms + shadow_b_ms) if have_split else kernel_ms) / args.steps / 1e3
 
     if rank == 0:
         # CPU leg (rank 0 only): the oracle on every 12th row of the same frame.  It is the CPU baseline, and its
@@ -210,7 +220,8 @@ def main():
                           "shadow_box_tests": cst.shadow_box_tests, "shadow_triangle_tests": cst.shadow_triangle_tests,
                           "box_tests": cst.box_tests, "triangle_tests": cst.triangle_tests, "rays": cst.total_rays()}
         if have_split:
-            dom_name = "k_stream<false, false, 2> (shadow pass)"
+            dom_name = ("k_stream<false, false, 2> (shadow pass) + k_stream<false, false, 1> (the second, small lighting round on the "
+                        "library's own stream): kernel_ms is the sum of the two launches' durations, the test counts cover both")
             dom_key = "k_stream<false, false, 2>"
             alg_flops = 27 * ref_counts["shadow_box_tests"] + 150 * ref_counts["shadow_triangle_tests"]
             alg_bytes = 44 * ref_counts["shadow_rays"] + 32 * ref_counts["shadow_box_tests"] + 36 * ref_counts["shadow_triangle_tests"]
@@ -258,31 +269,47 @@ def main():
             "frame_ms": frame_ms,
             "reference_workload_mrays_per_s": rays / elapsed / 1e6,
             # The dominant kernel against the roofs that can bind it.  Its working set (hierarchy + primitives, about
-            # 10 MB) stays in the caches, so HBM is not its roof (hbm.frac below, from the measured traffic); it is
-            # bound by vector-instruction issue, so the headline fraction is fp32 VALU.  No fraction uses a numerator
-            # other than what its field says.
+            # 10 MB) stays in the caches, so HBM is not its roof (hbm.frac below, from the measured traffic); its
+            # vector issue slots are 86 % in use (decomposition.valu_issue_util), so the headline fraction is fp32
+            # VALU.  No fraction uses a numerator other than what its field says.
             "roofline": {
                 "kernel": dom_name,
                 "bound": "valu",
-                "achieved": alg_flops / dom_s / 1e12,
+                # headline fraction: the tests the launches themselves perform (counted by the kernels) over the fp32 vector peak
+                "achieved": own_flops / dom_s / 1e12,
                 "peak": FP32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": alg_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS,
+                "frac": own_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS,
                 "traffic": traffic,
                 "kernel_ms": dom_s * 1e3,
-                "numerator": "27 flops per ray/box test + 150 per ray/triangle test (sqrt and divide counted as one each) over the tests of "
-                             "the shadow queries this launch answers (those whose light sample the surface faces); counts from: " + ref_counts["source"],
+                "numerator": "27 flops per ray/box test + 150 per ray/triangle test (sqrt and divide counted as one each) over the tests "
+                             "the shadow launches perform (any-hit: a query stops at its first accepted triangle), counted by the kernels "
+                             "in an untimed frame of the same workload",
                 "queries_per_launch": {"oracle": ref_counts["shadow_rays"], "kernel": cst.shadow_rays} if have_split else None,
-                "algorithmic_flops_per_launch": alg_flops,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "reference_workload": None if "all_shadow_box_tests" not in ref_counts or not have_split else {
-                    "note": "the same over ALL shadow queries of the reference's algorithm for this frame, including those the cull pass "
-                            "answers without a ray (not work of this launch; shown for scale only)",
-                    "flops": 27 * ref_counts["all_shadow_box_tests"] + 150 * ref_counts["all_shadow_triangle_tests"]},
-                "own_tests": {"note": "the same with the tests the kernel itself performs (any-hit: it stops a query at its first "
-                                      "accepted triangle, where the reference's closest-hit query goes on)",
-                              "flops_per_launch": own_flops, "bytes_per_launch": own_bytes,
-                              "achieved": own_flops / dom_s / 1e12, "frac": own_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS},
+                "algorithmic_flops_per_launch": own_flops,
+                "algorithmic_bytes_per_launch": own_bytes,
+                # the same against the peak this code can reach at all: no fused multiply-add by contract (bit-exact decisions)
+                "frac_of_no_fma_peak": own_flops / dom_s / 1e12 / FP32_NO_FMA_TFLOPS,
+                "no_fma_peak": FP32_NO_FMA_TFLOPS,
+                # what the fraction is made of (counters of the committed profile of this command, see counters_from)
+                "decomposition": None if not dom_counters.get("valu_issue_util") else {
+                    "valu_issue_util": round(dom_counters["valu_issue_util"], 3),
+                    "active_lane_frac": round(dom_counters["active_lane_frac"], 3),
+                    "useful_flops_per_issued_lane_op": round(own_flops / (dom_counters["valu_insts_per_launch"] * 64.0 * dom_counters["active_lane_frac"]), 3),
+                    "lane_ops_per_box_test": round(dom_counters["valu_insts_per_launch"] * 64.0 / max(1, cst.shadow_box_tests), 1),
+                    "note": "valu_issue_util = SQ_INSTS_VALU x 4 / (1024 SIMDs x kernel cycles): share of the chip's vector issue slots in use; "
+                            "active_lane_frac = lanes enabled per issued instruction; useful flops per issued lane operation = algorithmic flops "
+                            "/ (vector instructions x 64 x active lanes): the rest is addressing, compaction, votes and the stream's bookkeeping; "
+                            "the peak counts 2 flops per lane operation (fused multiply-add) and 2 lanes' worth per packed instruction, neither "
+                            "of which non-contracted scalar code can use (only the slab subtract/multiply of the box test is packed)"},
+                "reference_order": None if "all_shadow_box_tests" not in ref_counts or not have_split else {
+                    "note": "the same with the oracle's counts for the queries these launches answer, each traced as the reference does (a "
+                            "closest-hit query in its traversal order) - the algorithm's own work rather than this implementation's; and over "
+                            "ALL shadow queries of the reference's algorithm, including those the cull pass answers without a ray (for scale only)",
+                    "flops_per_launch": alg_flops, "bytes_per_launch": alg_bytes,
+                    "achieved": alg_flops / dom_s / 1e12, "frac": alg_flops / dom_s / 1e12 / FP32_PEAK_TFLOPS,
+                    "all_queries_flops": 27 * ref_counts["all_shadow_box_tests"] + 150 * ref_counts["all_shadow_triangle_tests"],
+                    "counts_from": ref_counts["source"]},
                 "hbm": None if traffic is None else {"achieved": traffic / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                      "frac": traffic / dom_s / 1e9 / HBM_PEAK_GBS, "source": "FETCH_SIZE / WRITE_SIZE passes, profiles/traffic.json"},
                 "l2": None if l2_req is None else {"read_requests_per_launch": l2_req, "achieved_at_64B": l2_req * 64 / dom_s / 1e9,
@@ -294,6 +321,7 @@ def main():
                                                                    if "active_lane_frac" in counters["per_kernel"].get(k, {})},
                 "counters_from": None if counters is None else counters.get("source"),
                 "all_kernels": {"kernel_ms": avg_kernel_s * 1e3, "primary_ms": primary_ms / args.steps, "shadow_ms": shadow_ms / args.steps,
+                                "shadow_second_round_ms": shadow_b_ms / args.steps,
                                 "cull_ms": cull_ms / args.steps, "shade_ms": shade_ms / args.steps,
                                 "own_tests_bytes": algorithmic_bytes(cst, my_pixels), "own_tests_flops": algorithmic_flops(cst)},
                 "stream_steps": {"packets": cst.stream_packets, "box_steps": cst.stream_box_steps, "primitive_steps": cst.stream_prim_steps,
@@ -353,6 +381,11 @@ def cpu_baseline(rt, scene, cam, feats, params):
         "sample": f"every {CPU_ROW_STEP}th row ({rows} rows) of the same {WIDTH}x{HEIGHT} frame at full sample count ({st.total_rays()} rays, {dt:.1f} s, OpenMP schedule(guided) over rows)",
         "frame_ms_extrapolated": dt * HEIGHT / rows * 1e3,
         "compare_with": "reference_workload_mrays_per_s (the CPU leg traces every shadow query of the reference's algorithm)",
+        "reference_as_is_ratio": REFERENCE_AS_IS_RATIO,
+        "reference_as_is_note": "the compiled reference as it is takes this many times the oracle's time on this benchmark's mesh (one thread "
+                                "each, 48x27 pixels at 16 spp, build container, tools/time_reference_headline.py): it copies the whole Mesh "
+                                "per leaf primitive it tests (src/bounding_volume_hierarchy.cpp:339); value / reference_as_is_ratio is the "
+                                "reference's own rate per thread-equivalent",
         "_stats": st,
         "_lit": lit,
         "_scale": HEIGHT / float(rows),
@@ -391,10 +424,28 @@ def extra_large_mesh(rt, synth, lib, cam, feats, params, out, stream):
     for _ in range(4):
         _, st = lib.render(bvh, cam, lights, n_lights, feats, params, WIDTH, HEIGHT, 0, HEIGHT, out=out.data_ptr(), device_ptr=1, stream=stream)
         best = st.kernel_ms + st.resolve_ms if best is None else min(best, st.kernel_ms + st.resolve_ms)
-    return {"triangles": scene.n_triangles, "bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)), "host_build_s": build_s,
-            "frame_ms": best, "mrays_per_s": st.total_rays() / best / 1e3, "reference_workload_mrays_per_s": st.reference_rays() / best / 1e3,
-            "primary_ms": st.primary_ms, "cull_ms": st.cull_ms, "shadow_ms": st.shadow_ms, "shade_ms": st.shade_ms,
-            "note": "device time of rt_render (HIP events), best of 4"}
+    out_d = {"triangles": scene.n_triangles, "bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)), "host_build_s": build_s,
+             "frame_ms": best, "mrays_per_s": st.total_rays() / best / 1e3, "reference_workload_mrays_per_s": st.reference_rays() / best / 1e3,
+             "primary_ms": st.primary_ms, "cull_ms": st.cull_ms, "shadow_ms": st.shadow_ms, "shade_ms": st.shade_ms,
+             "note": "device time of rt_render (HIP events), best of 4"}
+    # the shadow pass of this frame against the memory roofs, from the committed counters of the same frame (131 MB of
+    # hierarchy and primitives: beyond the L2 caches)
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_l8.json")) as f:
+            k = json.load(f)["per_kernel"]["k_stream<false, false, 2>"]
+        sec = st.shadow_ms / 1e3
+        out_d["shadow_pass"] = {
+            "hbm": {"bytes_per_launch": k["hbm_bytes_per_launch"], "achieved": k["hbm_bytes_per_launch"] / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": k["hbm_bytes_per_launch"] / sec / 1e9 / HBM_PEAK_GBS,
+                    "note": "FETCH_SIZE / WRITE_SIZE count what leaves the L2 caches; part of it is served by the 256 MB Infinity Cache, so this is an upper bound of the HBM share"},
+            "l2": {"read_requests_per_launch": k["l2_read_requests_per_launch"], "achieved_at_128B": k["l2_read_requests_per_launch"] * 128 / sec / 1e9,
+                   "peak": L2_PEAK_GBS, "unit": "GB/s", "frac_at_64B": k["l2_read_requests_per_launch"] * 64 / sec / 1e9 / L2_PEAK_GBS,
+                   "frac_at_128B": k["l2_read_requests_per_launch"] * 128 / sec / 1e9 / L2_PEAK_GBS},
+            "valu_issue_util": round(k["valu_issue_util"], 3), "active_lane_frac": round(k["active_lane_frac"], 3),
+            "counters_from": "profiles/r3_l8/summary.txt (profiles/traffic_l8.json)"}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out_d
 
 
 if __name__ == "__main__":

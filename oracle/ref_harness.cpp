@@ -862,7 +862,29 @@ int main(int argc, char** argv)
         }
         return 0;
     }
-    if (argc < 2) { std::fprintf(stderr, "usage: ref_dump <outdir> [data dir] | --time [data dir]\n"); return 2; }
+    if (argc == 6 && std::string(argv[1]) == "--time-obj") {
+        // ref_dump --time-obj <file.obj> <width> <height> <n>: the same wall time for any mesh under the benchmark's
+        // parallelogram light (the reference's Cornell light, src/scene.cpp:45-53, lifted to y = 1.2), shading + soft
+        // shadows, n x n samples per pixel, default camera.  Prints "<triangles> <width> <height> <n> <ms>".
+        Scene scene;
+        scene.meshes = loadMesh(argv[2], false);
+        scene.lights.emplace_back(ParallelogramLight { glm::vec3 { -0.2f, 1.2f, -0.2f }, glm::vec3 { 0.4f, 0.0f, 0.0f }, glm::vec3 { 0.0f, 0.0f, 0.4f },
+            glm::vec3 { 1, 0, 0 }, glm::vec3 { 0, 1, 0 }, glm::vec3 { 0, 0, 1 }, glm::vec3 { 1, 1, 1 } });
+        const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), n = std::atoi(argv[5]);
+        size_t triangles = 0;
+        for (const Mesh& m : scene.meshes) triangles += m.triangles.size();
+        Features f = feat(true, false, false, true, false, false);
+        f.extra.enableMultipleRaysPerPixel = n > 1;
+        BvhInterface bvh(&scene, f);
+        RenderOpts o; o.rayMultiplier = n;
+        rayMultiplier = n;
+        auto t0 = std::chrono::steady_clock::now();
+        auto img = render_image(scene, bvh, CAM_A, W, H, f, o);
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::printf("%zu %d %d %d %.1f\n", triangles, W, H, n, ms);
+        return 0;
+    }
+    if (argc < 2) { std::fprintf(stderr, "usage: ref_dump <outdir> [data dir] | --time [data dir] | --time-obj <obj> <width> <height> <n>\n"); return 2; }
     g_out = argv[1];
     std::filesystem::create_directories(g_out);
     std::filesystem::path dataDir = argc > 2 ? argv[2] : DATA_DIR;

@@ -1,5 +1,5 @@
-"""profiles/make_traffic.py <tag>: writes profiles/traffic.json from profiles/<tag>/summary.txt (the FETCH_SIZE and
-WRITE_SIZE passes of profiles/run_profile.sh).  Check on a known byte count: k_resolve reads 16 sample planes of
+"""profiles/make_traffic.py <tag> [output.json]: writes profiles/traffic.json (or the named file under profiles/) from
+profiles/<tag>/summary.txt (the FETCH_SIZE and WRITE_SIZE passes of profiles/run_profile.sh).  Check on a known byte count: k_resolve reads 16 sample planes of
 1920 x 1080 x 12 B = 398 MB, and 2 x FETCH_SIZE x 1024 gives 398 MB."""
 import json
 import os
@@ -8,7 +8,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 tag = sys.argv[1]
+out_name = sys.argv[2] if len(sys.argv) > 2 else "traffic.json"
 txt = open(os.path.join(HERE, tag, "summary.txt")).read()
+command = txt.splitlines()[0].replace("command: ", "") if txt.startswith("command: ") else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 
 
 def grab(section, counter):
@@ -48,8 +50,8 @@ for k in per_kernel:
             per_kernel[k][name] = table[k]
 frame = ["k_primary<true, false>", "k_stream<false, true, 1>", "k_closest<true, false>", "k_cull", "k_stream<false, false, 2>", "k_shade", "k_resolve"]
 doc = {
-    "source": "profiles/%s/summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, of `python3 bench.py "
-              "--steps 3 --warmup 1 --no-cpu-baseline` on one MI355X; per-dispatch averages" % tag,
+    "source": "profiles/%s/summary.txt: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one run each, of `%s` on one MI355X; "
+              "per-dispatch averages" % (tag, command),
     "counters": "l2_read_requests = TCP_TCC_READ_REQ_sum (requests of 64 or 128 bytes); active_lane_frac = "
                 "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU); instruction counts are wave instructions; valu_issue_util = "
                 "SQ_INSTS_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32 shader engines)",
@@ -60,5 +62,5 @@ doc = {
     "dominant_kernel_hbm_bytes_per_launch": per_kernel["k_stream<false, false, 2>"]["hbm_bytes_per_launch"],
     "hbm_bytes_per_frame": sum(per_kernel[k]["hbm_bytes_per_launch"] for k in frame if k in per_kernel),
 }
-json.dump(doc, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
+json.dump(doc, open(os.path.join(HERE, out_name), "w"), indent=1)
 print(doc["dominant_kernel_hbm_bytes_per_launch"], doc["hbm_bytes_per_frame"])

@@ -2,6 +2,8 @@
 # Profiling recipe used for the summaries under profiles/ (run on the GPU box through gpurun):
 #   profiles/run_profile.sh <tag> [passes...]      passes: trace sq1 sq2 tcc fetch write (default: all)
 # Pass "trace": kernel trace + stats.  The others: PMC counters, each in a run of its own (no tracing).
+# PROFILE_CMD names another command than the default headline bench (it must start with the program itself: python3 ...),
+# e.g. PROFILE_CMD="python3 tools/render_config4.py transparent_cornell" profiles/run_profile.sh r3_c4
 set -u
 TAG=${1:-r1}
 shift
@@ -10,7 +12,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+BENCH=${PROFILE_CMD:-"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"}
+echo "command: $BENCH" > $OUT/command.txt
 for p in $PASSES; do
   case $p in
     trace) ARGS="--kernel-trace --stats" ;;
@@ -22,5 +25,5 @@ for p in $PASSES; do
   esac
   timeout -s KILL 300 rocprofv3 $ARGS --output-format csv -d $OUT/$p -- $BENCH > $OUT/$p.log 2>&1 || exit 1
 done
-python3 profiles/summarize.py $OUT > $OUT/summary.txt
+{ cat $OUT/command.txt; python3 profiles/summarize.py $OUT; } > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -68,7 +68,7 @@ def test_eight_ranks_headline_workload(tmp_path):
     assert out["n_gpus"] == 8 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
     assert out["value"] > 0 and out["ms_per_step"] > 0
     roof = out["roofline"]
-    assert roof["bound"] == "valu" and 0 < roof["frac"] <= 1 and 0 < roof["own_tests"]["frac"] <= 1
+    assert roof["bound"] == "valu" and 0 < roof["frac"] <= 1 and 0 < roof["frac_of_no_fma_peak"] <= 1
     assert "interleaved 16-row blocks over 8 ranks" in out["config"]["partition"]
     ref, stats = _single_process_frame("c3")
     assert out["config"]["rays_per_frame"] == stats.total_rays()  # the ranks' shares add up to the whole frame's rays
