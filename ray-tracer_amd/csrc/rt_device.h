@@ -145,7 +145,8 @@ enum {
     Q_WF_OVERFLOW = Q_WF_GLOSSY + 16, // set when a generation did not fit the node or glossy capacity
     Q_RANGE_BEGIN = Q_WF_OVERFLOW + 16, // lighting passes (cull / shadow / shade): the hit-queue entries they work on,
     Q_RANGE_END = Q_RANGE_BEGIN + 16,   // set by k_range once the entries exist
-    Q_COUNT = Q_RANGE_END + 16
+    Q_SHADOW_XCD = Q_RANGE_END + 16,    // 8 cursors (one per 128-byte line): shadow packets handed out per eighth of the queue
+    Q_COUNT = Q_SHADOW_XCD + 8 * 16
 };
 
 struct Counts {

@@ -456,6 +456,9 @@ template <int G> struct PairEntry {
 };
 constexpr int STREAM_PER_LEVEL = 128;                     // stack entries per inner tree level
 constexpr int STREAM_LEAF_CAP = 192;                      // < 64 waiting + 128 from one step
+#ifndef RT_XCD_PACKETS
+#define RT_XCD_PACKETS 1
+#endif
 #ifndef RT_LEAF_TRIGGER
 #define RT_LEAF_TRIGGER 64
 #endif
@@ -618,13 +621,36 @@ __global__ void __launch_bounds__(WAVE, 5) k_stream(const FrameParams P)
     const lds_bytes stageLds = (lds_bytes)stage;
     const f32x4* staged = reinterpret_cast<const f32x4*>(stage + (lane & 3) * STREAM_STAGE_STRIDE + (lane >> 2) * 64);
     const uint32_t quarter = uint32_t(lane & 3) * 16u;
-    // Packets of 64 consecutive queued queries come from a cursor.
+    // Packets of 64 consecutive queued queries come from a cursor.  The shadow pass has eight of them, one per eighth of
+    // the queue, and a wave starts with the eighth of its own XCD: the queue is in hit order, i.e. in image order, so an
+    // XCD's waves work on one region of the scene and its L2 cache holds that region's part of the hierarchy instead of
+    // a slice of everything.  A wave whose eighth has run out goes on with the next one, so nobody idles.
+    const unsigned long long perEighth = (nPackets + 7ull) / 8ull;
+    // (hardware register XCC_ID, bits 3:0: the XCD this wave runs on)
+    const uint32_t home = (PRIMARY || !RT_XCD_PACKETS) ? 0u : uint32_t(__builtin_amdgcn_s_getreg((3 << 11) | 20)) & 7u;
+    uint32_t eighthsDone = 0;
     while (true) {
-        unsigned long long grabbed = 0;
-        if (lane == 0) grabbed = atomicAdd(&counters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
-        // (the same in every lane: kept in scalar registers)
-        const unsigned long long pk = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed))))
-            | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed >> 32)))) << 32);
+        unsigned long long pk = nPackets;
+        if (PRIMARY || !RT_XCD_PACKETS) {
+            unsigned long long grabbed = 0;
+            if (lane == 0) grabbed = atomicAdd(&counters[PRIMARY ? Q_GAVE_UP_PACKETS : Q_SHADOW_PACKETS], 1ull);
+            // (the same in every lane: kept in scalar registers)
+            pk = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed))))
+                | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed >> 32)))) << 32);
+        } else {
+            while (eighthsDone < 8u) {
+                const uint32_t x = (home + eighthsDone) & 7u;
+                unsigned long long grabbed = 0;
+                if (lane == 0) grabbed = atomicAdd(&counters[Q_SHADOW_XCD + 16 * x], 1ull);
+                const unsigned long long g = (unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed))))
+                    | ((unsigned long long)uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(grabbed >> 32)))) << 32);
+                if (g < perEighth && x * perEighth + g < nPackets) {
+                    pk = x * perEighth + g;
+                    break;
+                }
+                eighthsDone++;
+            }
+        }
         if (pk >= nPackets) break;
         if (COUNT) nPacketsDone++;
         // ---- this lane's query; the ones that pass the root gate start as pairs (ray, root)

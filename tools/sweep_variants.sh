@@ -4,7 +4,7 @@ settings=$1; shift
 for v in "$@"; do
   lib=$PWD/build_variants/librt_amd_$v.so
   [ "$v" = product ] && lib=$PWD/ray-tracer_amd/csrc/librt_amd.so
-  env $settings RT_AMD_LIBRARY=$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra > gpurun_out/sweep.log 2>&1 || { echo "$v: FAILED"; tail -3 gpurun_out/sweep.log; exit 1; }
+  env $settings RT_AMD_LIBRARY=$lib timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-extra $BENCH_ARGS > gpurun_out/sweep.log 2>&1 || { echo "$v: FAILED"; tail -3 gpurun_out/sweep.log; exit 1; }
   python3 - "$v $settings" <<PY
 import json,sys
 d=json.loads([l for l in open("gpurun_out/sweep.log") if l.startswith("{")][-1])
