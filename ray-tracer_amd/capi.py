@@ -383,8 +383,8 @@ class Library:
         return h
 
     def bvh_build_device(self, scene_handle, sah=False, max_level=32, sah_bins=64):
-        """rt_bvh_build_device: the same hierarchy with the per-level sorts on the GPU (falls back to the host sorts
-        where equal keys meet at a cut); returns (handle, sorted_on_device)."""
+        """rt_bvh_build_device: the same hierarchy built on the GPU (host build for the SAH variant and a few other
+        cases); returns (handle, built_on_device)."""
         h = C.c_void_p()
         opt = BvhOptions(int(sah), max_level, sah_bins)
         self.check(self.lib.rt_bvh_build_device(scene_handle, C.byref(opt), C.byref(h)))

@@ -92,13 +92,12 @@ struct Builder {
     bool sah;
     int spawnLevels; // subtrees above this level are built by a thread of their own
     size_t spawnMinimum;
-    bool presorted = false; // `order` already is the final leaf order (per-level sorts done elsewhere): ranges are only cut
 
     static Bounds empty() { return { splat3(FLT_MAX), splat3(-FLT_MAX) }; }
     static void grow(Bounds& b, const PrimBounds& p)
     {
-        b.lo = make3(std::fmin(b.lo.x, p.lo.x), std::fmin(b.lo.y, p.lo.y), std::fmin(b.lo.z, p.lo.z));
-        b.hi = make3(std::fmax(b.hi.x, p.hi.x), std::fmax(b.hi.y, p.hi.y), std::fmax(b.hi.z, p.hi.z));
+        b.lo = make3(min_first(b.lo.x, p.lo.x), min_first(b.lo.y, p.lo.y), min_first(b.lo.z, p.lo.z));
+        b.hi = make3(max_first(b.hi.x, p.hi.x), max_first(b.hi.y, p.hi.y), max_first(b.hi.z, p.hi.z));
     }
     Bounds bounds(size_t first, size_t last) const
     {
@@ -232,7 +231,7 @@ struct Builder {
         if (sah) {
             split = sahSplit(first, last, box);
         } else {
-            if (!presorted) sortAxis(first, last, level % 3);
+            sortAxis(first, last, level % 3);
             split = count / 2;
         }
         out.nodes.push_back(rec);
@@ -276,55 +275,6 @@ struct Builder {
 
 void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out)
 {
-    build_bvh(scene, opt, out, nullptr);
-}
-
-void reference_sort(int* indices, size_t count, const float* centroids, int axis)
-{
-    // the same element type, comparator and std::sort instantiation as Builder::sortAxis: same moves on equal keys
-    struct Keyed {
-        float key;
-        int index;
-    };
-    std::vector<Keyed> keyed(count);
-    for (size_t i = 0; i < count; i++) keyed[i] = { centroids[size_t(indices[i]) * 3 + size_t(axis)], indices[i] };
-    std::sort(keyed.begin(), keyed.end(), [](const Keyed& a, const Keyed& b) { return a.key < b.key; });
-    for (size_t i = 0; i < count; i++) indices[i] = keyed[i].index;
-}
-
-bool device_sort_applies(const HostScene& scene, const rt_bvh_options& opt)
-{
-    size_t total = scene.spheres.size();
-    for (const HostMesh& m : scene.meshes) total += m.triangles.size() / 3;
-    // one primitive per leaf is what makes the node ranges a function of the count alone: the level limit must not
-    // cut the tree short; the SAH variant chooses its cuts from the data
-    int levels = 0;
-    while ((size_t(1) << levels) < total) levels++;
-    return !opt.sah_binning && total >= 2 && levels <= opt.max_level;
-}
-
-void primitive_centroids(const HostScene& scene, std::vector<float>& centroids)
-{
-    centroids.clear();
-    for (const HostMesh& mesh : scene.meshes)
-        for (size_t t = 0; t < mesh.triangles.size() / 3; t++) {
-            const vec3 a = load3(&mesh.vertices[size_t(mesh.triangles[3 * t]) * 8]);
-            const vec3 b = load3(&mesh.vertices[size_t(mesh.triangles[3 * t + 1]) * 8]);
-            const vec3 c = load3(&mesh.vertices[size_t(mesh.triangles[3 * t + 2]) * 8]);
-            const vec3 sum = (a + b) + c; // the same operations as the primitive list below
-            centroids.push_back(sum.x / 3.0f);
-            centroids.push_back(sum.y / 3.0f);
-            centroids.push_back(sum.z / 3.0f);
-        }
-    for (const rt_sphere_desc& sp : scene.spheres) {
-        centroids.push_back(sp.center[0]);
-        centroids.push_back(sp.center[1]);
-        centroids.push_back(sp.center[2]);
-    }
-}
-
-void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out, const std::vector<int>* leafOrder)
-{
     out = HostBvh {};
     std::vector<PrimBounds> prims;
     size_t total = scene.spheres.size();
@@ -337,8 +287,8 @@ void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out, 
             const vec3 b = load3(&mesh.vertices[size_t(mesh.triangles[3 * t + 1]) * 8]);
             const vec3 c = load3(&mesh.vertices[size_t(mesh.triangles[3 * t + 2]) * 8]);
             PrimBounds p;
-            p.lo = make3(std::fmin(std::fmin(a.x, b.x), c.x), std::fmin(std::fmin(a.y, b.y), c.y), std::fmin(std::fmin(a.z, b.z), c.z));
-            p.hi = make3(std::fmax(std::fmax(a.x, b.x), c.x), std::fmax(std::fmax(a.y, b.y), c.y), std::fmax(std::fmax(a.z, b.z), c.z));
+            p.lo = make3(min_first(min_first(a.x, b.x), c.x), min_first(min_first(a.y, b.y), c.y), min_first(min_first(a.z, b.z), c.z));
+            p.hi = make3(max_first(max_first(a.x, b.x), c.x), max_first(max_first(a.y, b.y), c.y), max_first(max_first(a.z, b.z), c.z));
             const vec3 sum = (a + b) + c;
             p.centroid = make3(sum.x / 3.0f, sum.y / 3.0f, sum.z / 3.0f);
             p.prim = int32_t(t);
@@ -359,10 +309,6 @@ void build_bvh(const HostScene& scene, const rt_bvh_options& opt, HostBvh& out, 
     while ((1u << (spawnLevels + 1)) <= threads) spawnLevels++;
     Builder b { prims, std::vector<int>(prims.size()), opt.max_level, opt.sah_bins, opt.sah_binning != 0, spawnLevels, size_t(4096) };
     std::iota(b.order.begin(), b.order.end(), 0);
-    if (leafOrder && leafOrder->size() == prims.size()) {
-        b.order = *leafOrder;
-        b.presorted = true;
-    }
     Subtree tree;
     tree.nodes.reserve(prims.size() * 2 + 1);
     tree.prims.reserve(prims.size());

@@ -41,14 +41,6 @@ bool copy_scene(const rt_scene_desc& desc, HostScene& out, std::string& error);
 // Builds the hierarchy exactly as the reference's constructor does (median split per level axis, or the
 // SAH / binned-SAH variant), reference src/bounding_volume_hierarchy.cpp:41-208.
 void build_bvh(const HostScene& scene, const rt_bvh_options& options, HostBvh& out);
-// The same with the per-level sorts already done: `leafOrder` (primitive numbers in (mesh, triangle) then sphere order)
-// is the order the leaves hold them in; the builder only cuts ranges, makes the boxes and numbers the nodes.
-void build_bvh(const HostScene& scene, const rt_bvh_options& options, HostBvh& out, const std::vector<int>* leafOrder);
-// Whether the per-level sorts can be done apart from the builder (median variant, tree not cut short by the level limit).
-bool device_sort_applies(const HostScene& scene, const rt_bvh_options& options);
-// Centroids of the primitives (3 floats each) in the builder's primitive order, computed with its operations.
-void primitive_centroids(const HostScene& scene, std::vector<float>& centroids);
-
 struct FlatBvh {
     std::vector<NodeRec> nodes;
     std::vector<PrimRec> prims;
@@ -59,16 +51,25 @@ struct FlatBvh {
 };
 void flatten_bvh(const HostScene& scene, const HostBvh& bvh, FlatBvh& out);
 
-// std::sort of `count` primitive numbers by centroid coordinate exactly as the builder does it for a node (equal keys
-// end up where the builder's std::sort puts them, given the same input order).
-void reference_sort(int* indices, size_t count, const float* centroids, int axis);
-
-// (bvh_device.hip) The leaf order the reference's median-split build produces, by one segmented radix sort per level on
-// the current GPU.  A node where equal keys meet at its cut is sorted again on the host by reference_sort from the order
-// the node's primitives arrive in — which is known whenever their keys on the parent's axis are all different.
-// `ambiguous` is set instead when that is not the case (or a key is NaN, or there are very many such nodes): the
-// outcome then depends on the whole history of std::sort's moves and the host build must be used.  `hostFixed` counts
-// the nodes that were sorted again on the host.
-hipError_t device_split_order(const float* centroids, size_t count, std::vector<int>& order, bool& ambiguous, int* hostFixed = nullptr);
+// (bvh_device.hip) The same hierarchy built on the current GPU, tables left in device memory.  Pointers are hipMalloc'd
+// and owned by the struct's holder (release() frees what is still set).
+struct DeviceBvh {
+    NodeRec* nodes = nullptr;
+    PrimRec* prims = nullptr;
+    AttrRec* attrs = nullptr;
+    uint32_t* primOrder = nullptr;
+    rt_node_record* refNodes = nullptr; // the reference-order node list (what HostBvh::nodes holds after a host build)
+    rt_prim_ref* refPrims = nullptr;    // ... and its leaf primitive slots
+    size_t numInner = 0, numPrims = 0, numRefNodes = 0;
+    float rootLo[3] = { 0, 0, 0 }, rootHi[3] = { 0, 0, 0 };
+    int32_t rootRef = -1, numLevels = 0, numLeaves = 0;
+    void release();
+};
+// Median-split build of the reference (src/bounding_volume_hierarchy.cpp:41-208) on the current GPU, node for node the
+// tree build_bvh() makes: primitive boxes, the per-level std::sort calls reproduced move for move (including where
+// equal keys end up), node numbering, boxes and the device tables.  `unsupported` is set (and nothing built) for the
+// SAH variant, fewer than two primitives, a NaN centroid, leaves of more than 64 primitives (level limit), or a sort
+// that reaches introsort's depth limit: the caller uses the host builder then.
+hipError_t device_build(const HostScene& scene, const rt_bvh_options& options, DeviceBvh& out, bool& unsupported);
 
 } // namespace rt

@@ -1,176 +1,716 @@
-// The per-level sorts of the hierarchy build on the GPU.
+// The hierarchy build on the GPU: primitive boxes, the per-level sorts, node numbering, boxes, and the device tables
+// (node, primitive, attribute records) without a round trip through host memory.
 //
 // The reference's builder (src/bounding_volume_hierarchy.cpp:106-208, median variant) sorts the primitives of a node by
-// centroid coordinate on axis `level % 3` and hands the lower half (count / 2 primitives) to the left child.  Which
-// primitives end up in which half depends only on the keys, not on the sorting algorithm, unless equal keys straddle
-// the cut; and with one primitive per leaf the ranges of all nodes follow from the primitive count alone.  So the
-// whole build is a sequence of SEGMENTED sorts, one per level, the segments being the node ranges of that level: done
-// here as one radix sort per level on (segment number, order-preserving key bits), stable and therefore in general
-// NOT in std::sort's order among equal keys, which is why every cut is checked: if the two keys next to a cut compare
-// equal (as floats: -0 == +0), which primitives go left is std::sort's choice.  That choice is a function of the order
-// the node's primitives arrive in, and that order is known — it is the sorted order on the parent's axis — whenever
-// their keys on the parent's axis are pairwise different (the root's arrive in primitive order).  Such a node is sorted
-// again on the host with the builder's own std::sort and written back; anything else (arrival order not determined, a
-// NaN key, more ambiguous nodes than the list holds) makes the caller fall back to the host build.
+// centroid coordinate on axis `level % 3` with std::sort and hands the lower half (count / 2 primitives) to the left
+// child.  std::sort is not stable: where equal keys meet at a cut, which primitives go left is decided by the moves of
+// libstdc++'s introsort, and those depend on the order the node's primitives arrive in, i.e. on every sort above it.
+// The tree is therefore reproduced by running THE SAME ALGORITHM, move for move, as a data-parallel program:
+//
+//   * introsort's loop (median of three to the front, unguarded Hoare partition around it, both parts again until a
+//     part has 16 elements or fewer) runs in ROUNDS; a round partitions every part of every node of the level at once.
+//   * One Hoare partition as prefix sums.  With pivot p at the front of [first, last), the sequential loop pairs the
+//     j-th element from the left that is >= p with the j-th element from the right that is <= p and swaps them as long
+//     as the left one lies before the right one.  Position i holds the j-th ">=" from the left when j = number of
+//     ">=" in (first, i), and it is swapped exactly when more than j "<=" lie to its right; symmetrically for the right
+//     partners.  Two counts per position (one exclusive scan over packed pairs), a table "j -> position" for both
+//     sides, a binary search for the number of swaps k per part, and the swaps themselves are independent.  The
+//     returned cut is the smaller of the position of the (k+1)-th ">=" and that of the k-th right partner.
+//   * The final insertion sort of introsort never moves an element out of its part (everything in the part before is
+//     not greater), and an insertion sort is stable: it is a stable sort of each part of 16 or fewer elements, one
+//     thread per part.
+//   * A part that is still larger than 16 after 2 * floor(log2 n) partitions is heap-sorted by introsort (on meshes:
+//     a part of some twenty elements now and then).  libstdc++'s make_heap / sort_heap are run on it as they are, by one
+//     thread per such part.
+//
+// With the median cut the node ranges of every level follow from the primitive count alone (counts of a level differ
+// by at most one), so node numbers (depth-first pre-order, as the reference appends them), leaf slots and inner-node
+// ranks are closed-form from per-level tables of subtree sizes, and every node can be written by a thread of its own.
+// Boxes are combined bottom-up, a level per launch, left before right and keeping the earlier value on ties — which is
+// what the host builder's sequential fmin / fmax over the node's primitives yields (signed zeros included).
 #include "bvh_build.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <vector>
+
 namespace rt {
 
 namespace {
 
-// node range of `level` that position i belongs to: ranges are halved like the builder does (left = count / 2), a
-// range of fewer than two primitives is a leaf and stays as it is.  Returns the segment number (path bits).
-__device__ __forceinline__ uint32_t segment_of(uint32_t i, uint32_t n, int level, uint32_t& first, uint32_t& last)
+constexpr int SORT_THRESHOLD = 16; // libstdc++'s _S_threshold
+constexpr int TABLE_LEVELS = 34;
+constexpr int MAX_LEAF_PRIMS = 64; // leaves cut off by the level limit: a thread walks its leaf's primitives
+
+struct Keyed {
+    float key;
+    int index;
+};
+struct Seg { // one part of introsort's loop: [first, last) with `depth` partitions left before the limit
+    int first, last, depth, pad;
+};
+struct SegOut {
+    int k, cut, newL, newR;
+};
+struct Ctl {
+    int nActive[2];
+    int flags; // 1: a NaN key, 2: more or larger parts at introsort's depth limit than the heapsort kernel takes
+    int pad;
+    int nBlocks[TABLE_LEVELS];
+    int nHeaps[TABLE_LEVELS];
+};
+constexpr int MAX_HEAP_PARTS = 1024; // parts per level that reach introsort's depth limit (observed: none to a few)
+constexpr int MAX_HEAP_PART = 1 << 16; // ... and their size (observed: about 20 elements; a thread sorts one part)
+
+// Per-level tables of the median-split tree over n primitives.  Every node of level l holds cLo[l] or cLo[l] + 1
+// primitives; sub / leaves / inner = nodes, leaves and inner nodes of the subtree of such a node.
+struct Tables {
+    int n, depth, maxLevel; // depth = index of the deepest level
+    int cLo[TABLE_LEVELS];
+    int sub[TABLE_LEVELS][2], leaves[TABLE_LEVELS][2], inner[TABLE_LEVELS][2];
+};
+
+struct Geometry {
+    const float* verts;       // 8 floats per vertex, meshes one after the other
+    const uint32_t* tris;     // 3 indices per triangle (into the mesh's own vertices), meshes one after the other
+    const int* primBase;      // [nMeshes + 1] first primitive number of every mesh
+    const int* vertBase;      // [nMeshes] first vertex of every mesh
+    const rt_sphere_desc* spheres;
+    int nMeshes, nTriangles, nSpheres;
+};
+
+__device__ __forceinline__ int mesh_of(const Geometry& g, int prim)
 {
-    first = 0;
-    last = n;
-    uint32_t seg = 0;
+    int lo = 0, hi = g.nMeshes; // primBase[lo] <= prim < primBase[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (g.primBase[mid] <= prim) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ void triangle_vertices(const Geometry& g, int prim, int& mesh, const float*& va, const float*& vb, const float*& vc)
+{
+    mesh = mesh_of(g, prim);
+    const uint32_t* t = g.tris + size_t(prim) * 3;
+    const float* base = g.verts + size_t(g.vertBase[mesh]) * 8;
+    va = base + size_t(t[0]) * 8;
+    vb = base + size_t(t[1]) * 8;
+    vc = base + size_t(t[2]) * 8;
+}
+
+// Box and centroid of every primitive with the host builder's operations (build_bvh in bvh_build.cpp; reference
+// src/bounding_volume_hierarchy.cpp:21-31,61-76), and the identity permutation.
+__global__ void k_prim_bounds(const Geometry g, int n, float* __restrict__ lo, float* __restrict__ hi, float* __restrict__ centroid, Keyed* __restrict__ a, Ctl* ctl)
+{
+    const int p = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (p >= n) return;
+    vec3 l, h, c;
+    if (p < g.nTriangles) {
+        int mesh;
+        const float *va, *vb, *vc;
+        triangle_vertices(g, p, mesh, va, vb, vc);
+        const vec3 A = load3(va), B = load3(vb), C = load3(vc);
+        l = make3(min_first(min_first(A.x, B.x), C.x), min_first(min_first(A.y, B.y), C.y), min_first(min_first(A.z, B.z), C.z));
+        h = make3(max_first(max_first(A.x, B.x), C.x), max_first(max_first(A.y, B.y), C.y), max_first(max_first(A.z, B.z), C.z));
+        const vec3 sum = (A + B) + C;
+        c = make3(sum.x / 3.0f, sum.y / 3.0f, sum.z / 3.0f);
+    } else {
+        const rt_sphere_desc& s = g.spheres[p - g.nTriangles];
+        c = load3(s.center);
+        l = c - splat3(s.radius);
+        h = c + splat3(s.radius);
+    }
+    lo[3 * size_t(p)] = l.x; lo[3 * size_t(p) + 1] = l.y; lo[3 * size_t(p) + 2] = l.z;
+    hi[3 * size_t(p)] = h.x; hi[3 * size_t(p) + 1] = h.y; hi[3 * size_t(p) + 2] = h.z;
+    centroid[3 * size_t(p)] = c.x; centroid[3 * size_t(p) + 1] = c.y; centroid[3 * size_t(p) + 2] = c.z;
+    if (c.x != c.x || c.y != c.y || c.z != c.z) ctl->flags = 1;
+    a[p].index = p;
+}
+
+__device__ __forceinline__ int floor_log2(int v) { return 31 - __clz(v); }
+
+// Start of a level's sorts: the key of every element on the level's axis, the part table (one part per node of the
+// level that has more than 16 primitives, numbered by the node's path) and the nodes of 2..16 primitives as finished
+// parts.  The node of position i follows from halving [0, n) `level` times.
+__global__ void k_level_init(Keyed* __restrict__ a, const float* __restrict__ centroid, int* __restrict__ segOf, Seg* __restrict__ segs, int2* __restrict__ blocks, Ctl* ctl, int n, int level, int cur, int nActive)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i == 0) ctl->nActive[cur] = nActive;
+    if (i >= n) return;
+    int first = 0, count = n;
+    uint32_t path = 0;
+    bool split = true; // the node is reached (no ancestor is a leaf)
     for (int l = 0; l < level; l++) {
-        seg <<= 1;
-        if (last - first < 2u) continue;
-        const uint32_t mid = first + (last - first) / 2u;
-        if (i < mid) {
-            last = mid;
+        if (count <= 1) {
+            split = false;
+            break;
+        }
+        const int left = count / 2;
+        path <<= 1;
+        if (i < first + left) {
+            count = left;
         } else {
-            first = mid;
-            seg |= 1u;
+            first += left;
+            count -= left;
+            path |= 1u;
         }
     }
-    return seg;
-}
-
-// order-preserving bits of a float for an unsigned radix sort
-__device__ __forceinline__ uint32_t ordered_bits(float f)
-{
-    const uint32_t u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-__global__ void k_level_keys(const float* __restrict__ centroids, const int* __restrict__ order, uint32_t n, int level, unsigned long long* __restrict__ keys, int* flags)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t first, last;
-    const uint32_t seg = segment_of(i, n, level, first, last);
-    const float c = centroids[size_t(order[i]) * 3 + size_t(level % 3)];
-    if (c != c) flags[1] = 1; // a NaN coordinate: the host decides
-    keys[i] = ((unsigned long long)seg << 32) | ordered_bits(c);
-}
-
-// after the sort of `level`: every cut (the middle of a range of two or more) must separate different keys
-constexpr int MAX_TIED_NODES = 4096;
-
-// after the sort of `level`: the nodes whose cut (the middle of a range of two or more) separates equal keys
-__global__ void k_level_cuts(const float* __restrict__ centroids, const int* __restrict__ order, uint32_t n, int level, int* flags, uint2* tied)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || i == 0) return;
-    uint32_t first, last;
-    (void)segment_of(i, n, level, first, last);
-    if (last - first < 2u || i != first + (last - first) / 2u) return;
-    const int axis = level % 3;
-    if (centroids[size_t(order[i - 1]) * 3 + size_t(axis)] == centroids[size_t(order[i]) * 3 + size_t(axis)]) {
-        const int at = atomicAdd(&flags[0], 1);
-        if (at < MAX_TIED_NODES) tied[at] = make_uint2(first, last);
+    if (!split || count < 2) {
+        segOf[i] = -1;
+        return;
+    }
+    a[i].key = centroid[3 * size_t(a[i].index) + size_t(level % 3)];
+    const bool active = count > SORT_THRESHOLD;
+    segOf[i] = active ? int(path) : -1;
+    if (i == first) {
+        if (nActive > 0) segs[path] = active ? Seg { first, first + count, 2 * floor_log2(count), 0 } : Seg { 0, 0, 0, 0 };
+        if (!active) blocks[atomicAdd(&ctl->nBlocks[level], 1)] = make_int2(first, first + count);
     }
 }
 
-__global__ void k_iota(int* order, uint32_t n)
+// position of the median of a[first + 1], a[first + (last - first) / 2], a[last - 1] as __move_median_to_first picks it
+__device__ __forceinline__ int median_position(const Keyed* a, int first, int last)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[i] = int(i);
+    const int A = first + 1, B = first + (last - first) / 2, C = last - 1;
+    const float ka = a[A].key, kb = a[B].key, kc = a[C].key;
+    if (ka < kb) {
+        if (kb < kc) return B;
+        if (ka < kc) return C;
+        return A;
+    }
+    if (ka < kc) return A;
+    if (kb < kc) return C;
+    return B;
 }
 
-struct Buffers {
-    float* centroids = nullptr;
-    int *orderA = nullptr, *orderB = nullptr, *flags = nullptr;
-    unsigned long long *keysA = nullptr, *keysB = nullptr;
-    uint2* tied = nullptr;
-    void* temp = nullptr;
-    ~Buffers()
+// Round, step 1: per position its two flags (">= pivot" in the high word, "<= pivot" in the low word) as seen AFTER the
+// median has been swapped to the front (the swap itself is made in step 2, when nobody reads the keys).
+__global__ void k_round_flags(const Keyed* __restrict__ a, const int* __restrict__ segOf, const Seg* __restrict__ segs, unsigned long long* __restrict__ flags, const Ctl* ctl, int n, int cur)
+{
+    if (ctl->nActive[cur] == 0) return;
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    unsigned long long f = 0;
+    const int s = segOf[i];
+    if (s >= 0) {
+        const Seg sg = segs[s];
+        if (i != sg.first) {
+            const int m = median_position(a, sg.first, sg.last);
+            const float pivot = a[m].key;
+            const float key = i == m ? a[sg.first].key : a[i].key;
+            f = (key >= pivot ? 1ull << 32 : 0ull) | (key <= pivot ? 1ull : 0ull);
+        }
+    }
+    flags[i] = f;
+}
+
+// Round, step 2 (after the exclusive scan of the flags): the tables "j-th '>=' from the left -> position" and
+// "j-th '<=' from the right -> position" of every part, kept in the part's own index range.
+__global__ void k_round_ranks(Keyed* __restrict__ a, const int* __restrict__ segOf, const Seg* __restrict__ segs, const unsigned long long* __restrict__ scan, int* __restrict__ posL, int* __restrict__ posR, const Ctl* ctl, int n, int cur)
+{
+    if (ctl->nActive[cur] == 0) return;
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int s = segOf[i];
+    if (s < 0) return;
+    const Seg sg = segs[s];
+    if (i == sg.first) {
+        const int m = median_position(a, sg.first, sg.last);
+        const Keyed t = a[sg.first];
+        a[sg.first] = a[m];
+        a[m] = t;
+        return;
+    }
+    const unsigned long long here = scan[i], after = scan[i + 1], base = scan[sg.first + 1], end = scan[sg.last];
+    const bool ge = (after >> 32) != (here >> 32), le = uint32_t(after) != uint32_t(here);
+    if (ge) posL[sg.first + 1 + int((here >> 32) - (base >> 32))] = i;
+    if (le) posR[sg.first + 1 + int(uint32_t(end) - uint32_t(after))] = i;
+}
+
+// Round, step 3: per part the number of swaps, the cut, and the two parts it leaves.
+__global__ void k_round_cuts(const Seg* __restrict__ segs, Seg* __restrict__ next, SegOut* __restrict__ out, const unsigned long long* __restrict__ scan, const int* __restrict__ posL, const int* __restrict__ posR, int2* __restrict__ blocks, int2* __restrict__ heaps, Ctl* ctl, int level, int cur)
+{
+    const int s = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (s >= ctl->nActive[cur]) return;
+    const Seg sg = segs[s];
+    if (sg.last - sg.first <= SORT_THRESHOLD) return; // (a node of the level with exactly 16 primitives)
+    const unsigned long long base = scan[sg.first + 1], end = scan[sg.last];
+    const int nGe = int((end >> 32) - (base >> 32)), nLe = int(uint32_t(end) - uint32_t(base));
+    int lo = 0, hi = nGe < nLe ? nGe : nLe;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (posL[sg.first + mid] < posR[sg.first + mid]) lo = mid; else hi = mid - 1;
+    }
+    const int k = lo;
+    const int cutL = k < nGe ? posL[sg.first + 1 + k] : INT_MAX, cutR = k > 0 ? posR[sg.first + k] : INT_MAX;
+    const int cut = cutL < cutR ? cutL : cutR;
+    SegOut o { k, cut, -1, -1 };
+    for (int c = 0; c < 2; c++) {
+        const int f = c ? cut : sg.first, l = c ? sg.last : cut;
+        int id = -1;
+        if (l - f > SORT_THRESHOLD) {
+            if (sg.depth - 1 == 0) {
+                // introsort switches to heapsort here: the part is sorted by a thread of its own after the round
+                const int h = atomicAdd(&ctl->nHeaps[level], 1);
+                if (h < MAX_HEAP_PARTS && l - f <= MAX_HEAP_PART) heaps[level * MAX_HEAP_PARTS + h] = make_int2(f, l);
+                else ctl->flags = 2;
+            } else {
+                id = atomicAdd(&ctl->nActive[cur ^ 1], 1);
+                next[id] = Seg { f, l, sg.depth - 1, 0 };
+            }
+        } else {
+            blocks[atomicAdd(&ctl->nBlocks[level], 1)] = make_int2(f, l);
+        }
+        if (c) o.newR = id; else o.newL = id;
+    }
+    out[s] = o;
+}
+
+// Round, step 4: the swaps (made by the left partner) and the part every position belongs to in the next round.
+__global__ void k_round_swaps(Keyed* __restrict__ a, int* __restrict__ segOf, const Seg* __restrict__ segs, const SegOut* __restrict__ out, const unsigned long long* __restrict__ scan, const int* __restrict__ posR, Ctl* ctl, int n, int cur)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i == 0) ctl->nActive[cur] = 0; // (this round's table becomes the next round's output table)
+    if (i >= n) return;
+    const int s = segOf[i];
+    if (s < 0) return;
+    const Seg sg = segs[s];
+    const SegOut o = out[s];
+    if (i != sg.first) {
+        const unsigned long long here = scan[i], after = scan[i + 1], base = scan[sg.first + 1];
+        const int rankL = int((here >> 32) - (base >> 32));
+        if ((after >> 32) != (here >> 32) && rankL < o.k) {
+            const int partner = posR[sg.first + 1 + rankL];
+            const Keyed t = a[i];
+            a[i] = a[partner];
+            a[partner] = t;
+        }
+    }
+    segOf[i] = i < o.cut ? o.newL : o.newR;
+}
+
+// The final insertion sort: a stable sort of every finished part (2..16 elements).
+__global__ void k_sort_blocks(Keyed* __restrict__ a, const int2* __restrict__ blocks, const Ctl* ctl, int level)
+{
+    const int b = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (b >= ctl->nBlocks[level]) return;
+    const int2 r = blocks[b];
+    for (int i = r.x + 1; i < r.y; i++) {
+        const Keyed v = a[i];
+        int j = i;
+        while (j > r.x && v.key < a[j - 1].key) {
+            a[j] = a[j - 1];
+            j--;
+        }
+        a[j] = v;
+    }
+}
+
+
+// libstdc++'s heap sort of a part that reached introsort's depth limit: __partial_sort(first, last, last) =
+// __make_heap + __sort_heap, built on __adjust_heap / __push_heap (bits/stl_heap.h), with the same moves.
+__device__ void adjust_heap(Keyed* first, int hole, int len, Keyed value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (first[child].key < first[child - 1].key) child--;
+        first[hole] = first[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        first[hole] = first[child - 1];
+        hole = child - 1;
+    }
+    // __push_heap
+    int parent = (hole - 1) / 2;
+    while (hole > top && first[parent].key < value.key) {
+        first[hole] = first[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    first[hole] = value;
+}
+__global__ void k_heap_sorts(Keyed* __restrict__ a, const int2* __restrict__ heaps, const Ctl* ctl, int level)
+{
+    const int h = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (h >= ctl->nHeaps[level] || h >= MAX_HEAP_PARTS) return;
+    const int2 r = heaps[level * MAX_HEAP_PARTS + h];
+    Keyed* first = a + r.x;
+    const int len = r.y - r.x;
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; parent--) { // __make_heap
+        adjust_heap(first, parent, len, first[parent]);
+        if (parent == 0) break;
+    }
+    for (int last = len - 1; last >= 1; last--) { // __sort_heap: __pop_heap(first, last, last)
+        const Keyed value = first[last];
+        first[last] = first[0];
+        adjust_heap(first, 0, last, value);
+    }
+}
+
+// ---- nodes ------------------------------------------------------------------------------------------------------
+struct NodeAt {
+    int first, count, level;
+    int index;     // depth-first pre-order number
+    int innerRank; // inner nodes before it in that order
+    bool leaf;
+};
+__device__ __forceinline__ int table(const int (*t)[2], const Tables& T, int level, int count) { return t[level][count - T.cLo[level]]; }
+
+// the node with path bits `path` on `level`; false when an ancestor is a leaf
+__device__ __forceinline__ bool node_at(const Tables& T, int level, uint32_t path, NodeAt& nd)
+{
+    int first = 0, count = T.n, index = 0, innerRank = 0;
+    for (int l = 0; l < level; l++) {
+        if (count <= 1 || l == T.maxLevel) return false;
+        const int left = count / 2;
+        if (!((path >> (level - 1 - l)) & 1u)) {
+            index += 1;
+            innerRank += 1;
+            count = left;
+        } else {
+            index += 1 + table(T.sub, T, l + 1, left);
+            innerRank += 1 + table(T.inner, T, l + 1, left);
+            first += left;
+            count -= left;
+        }
+    }
+    nd = NodeAt { first, count, level, index, innerRank, count <= 1 || level == T.maxLevel };
+    return true;
+}
+__device__ __forceinline__ bool node_of_thread(const Tables& T, NodeAt& nd)
+{
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1ull; // 1-based heap number
+    if (t >> (T.depth + 1)) return false;
+    const int level = 63 - __clzll((long long)t);
+    return node_at(T, level, uint32_t(t - (1ull << level)), nd);
+}
+
+// Every node's record in the reference's order; leaves with their box (their primitives in order, as the builder's
+// bounds() walks them) and the `more` counts of their slots.
+__global__ void k_nodes(const Tables T, const Keyed* __restrict__ a, const float* __restrict__ lo, const float* __restrict__ hi, rt_node_record* __restrict__ nodes, int* __restrict__ more)
+{
+    NodeAt nd;
+    if (!node_of_thread(T, nd)) return;
+    rt_node_record rec;
+    rec.is_leaf = nd.leaf ? 1 : 0;
+    rec.level = nd.level;
+    for (int k = 0; k < 3; k++) {
+        rec.lower[k] = FLT_MAX;
+        rec.upper[k] = -FLT_MAX;
+    }
+    if (nd.leaf) {
+        rec.a = nd.first;
+        rec.b = nd.count;
+        for (int j = 0; j < nd.count; j++) {
+            const size_t p = size_t(a[nd.first + j].index);
+            for (int k = 0; k < 3; k++) {
+                rec.lower[k] = min_first(rec.lower[k], lo[3 * p + k]);
+                rec.upper[k] = max_first(rec.upper[k], hi[3 * p + k]);
+            }
+            more[nd.first + j] = nd.count - 1 - j;
+        }
+    } else {
+        rec.a = nd.index + 1;
+        rec.b = nd.index + 1 + table(T.sub, T, nd.level + 1, nd.count / 2);
+    }
+    nodes[nd.index] = rec;
+}
+
+// Boxes of the inner nodes of one level from their children's.
+__global__ void k_boxes(const Tables T, int level, rt_node_record* __restrict__ nodes)
+{
+    const uint32_t path = blockIdx.x * blockDim.x + threadIdx.x;
+    if (path >> level) return;
+    NodeAt nd;
+    if (!node_at(T, level, path, nd) || nd.leaf) return;
+    rt_node_record& rec = nodes[nd.index];
+    const rt_node_record &L = nodes[rec.a], &R = nodes[rec.b];
+    for (int k = 0; k < 3; k++) {
+        rec.lower[k] = min_first(L.lower[k], R.lower[k]);
+        rec.upper[k] = max_first(L.upper[k], R.upper[k]);
+    }
+}
+
+// The device table of inner nodes (flatten_bvh in bvh_build.cpp).
+__global__ void k_flatten(const Tables T, const rt_node_record* __restrict__ nodes, NodeRec* __restrict__ out)
+{
+    NodeAt nd;
+    if (!node_of_thread(T, nd) || nd.leaf) return;
+    const rt_node_record& rec = nodes[nd.index];
+    const rt_node_record &L = nodes[rec.a], &R = nodes[rec.b];
+    NodeRec d;
+    for (int k = 0; k < 3; k++) {
+        d.boxL[2 * k] = L.lower[k]; d.boxL[2 * k + 1] = L.upper[k];
+        d.boxR[2 * k] = R.lower[k]; d.boxR[2 * k + 1] = R.upper[k];
+    }
+    d.refL = L.is_leaf ? ~L.a : nd.innerRank + 1;
+    d.refR = R.is_leaf ? ~R.a : nd.innerRank + 1 + table(T.inner, T, nd.level + 1, nd.count / 2);
+    d.level = nd.level;
+    d.refNode = nd.index;
+    out[nd.innerRank] = d;
+}
+
+// Primitive and attribute records in leaf order, the (triangle, mesh) list of the leaves and the brute-force order.
+__global__ void k_prim_records(const Geometry g, int n, const Keyed* __restrict__ a, const int* __restrict__ more, PrimRec* __restrict__ prims, AttrRec* __restrict__ attrs, rt_prim_ref* __restrict__ refs, uint32_t* __restrict__ primOrder)
+{
+    const int slot = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (slot >= n) return;
+    const int p = a[slot].index;
+    PrimRec r;
+    AttrRec at;
+    memset(&r, 0, sizeof r);
+    memset(&at, 0, sizeof at);
+    r.more = more[slot];
+    if (p < g.nTriangles) {
+        int mesh;
+        const float *va, *vb, *vc;
+        triangle_vertices(g, p, mesh, va, vb, vc);
+        const vec3 v0 = load3(va), v1 = load3(vb), v2 = load3(vc);
+        r.mesh = mesh;
+        r.prim = p - g.primBase[mesh];
+        for (int k = 0; k < 3; k++) {
+            r.v0[k] = va[k]; r.v1[k] = vb[k]; r.v2[k] = vc[k];
+            at.n0[k] = va[3 + k]; at.n1[k] = vb[3 + k]; at.n2[k] = vc[3 + k];
+        }
+        for (int k = 0; k < 2; k++) {
+            at.uv0[k] = va[6 + k]; at.uv1[k] = vb[6 + k]; at.uv2[k] = vc[6 + k];
+        }
+        // trianglePlane and pointInTriangle's total area, reference src/intersect.cpp:52-60,26
+        const vec3 nn = cross(v1 - v0, v2 - v0);
+        const vec3 normal = is_zero(length(nn)) ? make3(1.0f, 0.0f, 0.0f) : normalize(nn);
+        r.n[0] = normal.x; r.n[1] = normal.y; r.n[2] = normal.z;
+        r.invArea = 1.0f / length(cross(v0 - v2, v1 - v2));
+    } else {
+        const rt_sphere_desc& s = g.spheres[p - g.nTriangles];
+        r.mesh = -1;
+        r.prim = p - g.nTriangles;
+        r.v0[0] = s.center[0]; r.v0[1] = s.center[1]; r.v0[2] = s.center[2];
+        r.v1[0] = s.radius;
+    }
+    prims[slot] = r;
+    attrs[slot] = at;
+    refs[slot] = rt_prim_ref { r.prim, r.mesh };
+    primOrder[p] = uint32_t(slot);
+}
+
+bool make_tables(int n, int maxLevel, Tables& T)
+{
+    std::memset(&T, 0, sizeof T);
+    T.n = n;
+    T.maxLevel = maxLevel;
+    int depth = 0;
+    while (depth < maxLevel && ((n + (1 << depth) - 1) >> depth) > 1) depth++; // deepest level: every node has <= 1, or the limit
+    if (depth >= TABLE_LEVELS - 1) return false;
+    T.depth = depth;
+    for (int l = 0; l <= depth + 1; l++) T.cLo[l] = n >> l;
+    for (int l = depth; l >= 0; l--)
+        for (int k = 0; k < 2; k++) {
+            const int c = T.cLo[l] + k;
+            if (c <= 1 || l == maxLevel) {
+                T.sub[l][k] = 1;
+                T.leaves[l][k] = 1;
+                T.inner[l][k] = 0;
+            } else {
+                const int left = c / 2, right = c - left;
+                const int a = left - T.cLo[l + 1], b = right - T.cLo[l + 1];
+                T.sub[l][k] = 1 + T.sub[l + 1][a] + T.sub[l + 1][b];
+                T.leaves[l][k] = T.leaves[l + 1][a] + T.leaves[l + 1][b];
+                T.inner[l][k] = 1 + T.inner[l + 1][a] + T.inner[l + 1][b];
+            }
+        }
+    return true;
+}
+
+template <class T>
+hipError_t own(T*& p, size_t count)
+{
+    void* q = nullptr;
+    const hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+    p = static_cast<T*>(q);
+    return e;
+}
+
+struct Scratch {
+    std::vector<void*> all;
+    ~Scratch()
     {
-        for (void* p : { (void*)centroids, (void*)orderA, (void*)orderB, (void*)flags, (void*)keysA, (void*)keysB, (void*)tied, temp })
+        for (void* p : all)
             if (p) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t get(T*& p, size_t count)
+    {
+        void* q = nullptr;
+        const hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+        if (e == hipSuccess) all.push_back(q);
+        p = static_cast<T*>(q);
+        return e;
     }
 };
 
 } // namespace
 
-hipError_t device_split_order(const float* centroids, size_t count, std::vector<int>& order, bool& ambiguous, int* hostFixed)
+void DeviceBvh::release()
 {
-    ambiguous = false;
-    if (hostFixed) *hostFixed = 0;
-    order.resize(count);
-    if (count == 0) return hipSuccess;
-    if (count >= (size_t(1) << 31)) {
-        ambiguous = true;
-        return hipSuccess;
+    for (void** p : { (void**)&nodes, (void**)&prims, (void**)&attrs, (void**)&primOrder, (void**)&refNodes, (void**)&refPrims })
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+}
+
+hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, DeviceBvh& out, bool& unsupported)
+{
+    unsupported = true;
+    out = DeviceBvh {};
+    size_t nTriangles = 0, nVertices = 0;
+    for (const HostMesh& m : scene.meshes) {
+        nTriangles += m.triangles.size() / 3;
+        nVertices += m.vertices.size() / 8;
     }
-    const uint32_t n = uint32_t(count);
-    int levels = 0; // levels that have a range of two or more primitives
-    while ((size_t(1) << levels) < count) levels++;
-    Buffers b;
+    const size_t total = nTriangles + scene.spheres.size();
+    if (opt.sah_binning || total < 2 || total >= (size_t(1) << 28) || opt.max_level < 0 || opt.max_level >= TABLE_LEVELS - 1) return hipSuccess;
+    const int n = int(total);
+    Tables T;
+    if (!make_tables(n, opt.max_level, T)) return hipSuccess;
+    if (T.depth == opt.max_level && T.cLo[T.depth] + 1 > MAX_LEAF_PRIMS) return hipSuccess; // very large leaves: host
     hipError_t e;
 #define RT_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
-    RT_TRY(hipMalloc(&b.centroids, count * 12));
-    RT_TRY(hipMalloc(&b.orderA, count * sizeof(int)));
-    RT_TRY(hipMalloc(&b.orderB, count * sizeof(int)));
-    RT_TRY(hipMalloc(&b.keysA, count * sizeof(unsigned long long)));
-    RT_TRY(hipMalloc(&b.keysB, count * sizeof(unsigned long long)));
-    RT_TRY(hipMalloc(&b.flags, 2 * sizeof(int)));
-    RT_TRY(hipMalloc(&b.tied, MAX_TIED_NODES * sizeof(uint2)));
-    RT_TRY(hipMemcpy(b.centroids, centroids, count * 12, hipMemcpyHostToDevice));
-    RT_TRY(hipMemset(b.flags, 0, 2 * sizeof(int)));
-    size_t tempBytes = 0;
-    RT_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, b.keysA, b.keysB, b.orderA, b.orderB, int(n), 0, 64));
-    RT_TRY(hipMalloc(&b.temp, tempBytes ? tempBytes : 16));
-    const dim3 block(256), grid((n + 255u) / 256u);
-    hipLaunchKernelGGL(k_iota, grid, block, 0, nullptr, b.orderA, n);
-    int *cur = b.orderA, *next = b.orderB;
-    for (int level = 0; level < levels; level++) {
-        hipLaunchKernelGGL(k_level_keys, grid, block, 0, nullptr, b.centroids, cur, n, level, b.keysA, b.flags);
-        RT_TRY(hipcub::DeviceRadixSort::SortPairs(b.temp, tempBytes, b.keysA, b.keysB, cur, next, int(n), 0, 32 + (level > 0 ? level : 1)));
-        int* t = cur;
-        cur = next;
-        next = t; // (still holds the order the level's nodes received their primitives in)
-        hipLaunchKernelGGL(k_level_cuts, grid, block, 0, nullptr, b.centroids, cur, n, level, b.flags, b.tied);
-        RT_TRY(hipGetLastError());
-        int flags[2] = { 0, 0 };
-        RT_TRY(hipMemcpy(flags, b.flags, sizeof flags, hipMemcpyDeviceToHost));
-        if (flags[1] || flags[0] > MAX_TIED_NODES) {
-            ambiguous = true;
-            return hipSuccess;
-        }
-        if (flags[0] > 0) {
-            std::vector<uint2> tied;
-            tied.resize(size_t(flags[0]));
-            RT_TRY(hipMemcpy(tied.data(), b.tied, tied.size() * sizeof(uint2), hipMemcpyDeviceToHost));
-            std::vector<int> arrived;
-            for (const uint2& node : tied) {
-                const size_t first = node.x, len = size_t(node.y - node.x);
-                arrived.resize(len);
-                RT_TRY(hipMemcpy(arrived.data(), next + first, len * sizeof(int), hipMemcpyDeviceToHost));
-                if (level > 0) {
-                    // the arrival order is the sorted order on the parent's axis only if no two keys there are equal
-                    const int parentAxis = (level - 1) % 3;
-                    for (size_t i = 0; i + 1 < len; i++)
-                        if (!(centroids[size_t(arrived[i]) * 3 + size_t(parentAxis)] < centroids[size_t(arrived[i + 1]) * 3 + size_t(parentAxis)])) {
-                            ambiguous = true;
-                            return hipSuccess;
-                        }
-                }
-                reference_sort(arrived.data(), len, centroids, level % 3);
-                RT_TRY(hipMemcpy(cur + first, arrived.data(), len * sizeof(int), hipMemcpyHostToDevice));
-                if (hostFixed) (*hostFixed)++;
-            }
-            RT_TRY(hipMemset(b.flags, 0, sizeof(int)));
-        }
+    Scratch tmp;
+    // ---- geometry
+    float* dVerts;
+    uint32_t* dTris;
+    int *dPrimBase, *dVertBase;
+    rt_sphere_desc* dSpheres;
+    RT_TRY(tmp.get(dVerts, nVertices * 8));
+    RT_TRY(tmp.get(dTris, nTriangles * 3));
+    RT_TRY(tmp.get(dPrimBase, scene.meshes.size() + 1));
+    RT_TRY(tmp.get(dVertBase, scene.meshes.size() + 1));
+    RT_TRY(tmp.get(dSpheres, scene.spheres.size()));
+    std::vector<int> primBase(scene.meshes.size() + 1, 0), vertBase(scene.meshes.size() + 1, 0);
+    for (size_t m = 0; m < scene.meshes.size(); m++) {
+        const HostMesh& mesh = scene.meshes[m];
+        if (!mesh.vertices.empty()) RT_TRY(hipMemcpyAsync(dVerts + size_t(vertBase[m]) * 8, mesh.vertices.data(), mesh.vertices.size() * sizeof(float), hipMemcpyHostToDevice, nullptr));
+        if (!mesh.triangles.empty()) RT_TRY(hipMemcpyAsync(dTris + size_t(primBase[m]) * 3, mesh.triangles.data(), mesh.triangles.size() * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+        primBase[m + 1] = primBase[m] + int(mesh.triangles.size() / 3);
+        vertBase[m + 1] = vertBase[m] + int(mesh.vertices.size() / 8);
     }
-    RT_TRY(hipMemcpy(order.data(), cur, count * sizeof(int), hipMemcpyDeviceToHost));
+    RT_TRY(hipMemcpyAsync(dPrimBase, primBase.data(), primBase.size() * sizeof(int), hipMemcpyHostToDevice, nullptr));
+    RT_TRY(hipMemcpyAsync(dVertBase, vertBase.data(), vertBase.size() * sizeof(int), hipMemcpyHostToDevice, nullptr));
+    if (!scene.spheres.empty()) RT_TRY(hipMemcpyAsync(dSpheres, scene.spheres.data(), scene.spheres.size() * sizeof(rt_sphere_desc), hipMemcpyHostToDevice, nullptr));
+    const Geometry geo { dVerts, dTris, dPrimBase, dVertBase, dSpheres, int(scene.meshes.size()), int(nTriangles), int(scene.spheres.size()) };
+    // ---- sort state
+    float *dLo, *dHi, *dCentroid;
+    Keyed* a;
+    int *segOf, *posL, *posR, *more;
+    unsigned long long *flags, *scan;
+    Seg* segs[2];
+    SegOut* segOut;
+    int2 *blocks, *heaps;
+    Ctl* ctl;
+    const size_t maxSegs = size_t(n) / (SORT_THRESHOLD + 1) + 2;
+    RT_TRY(tmp.get(dLo, size_t(n) * 3));
+    RT_TRY(tmp.get(dHi, size_t(n) * 3));
+    RT_TRY(tmp.get(dCentroid, size_t(n) * 3));
+    RT_TRY(tmp.get(a, size_t(n)));
+    RT_TRY(tmp.get(segOf, size_t(n)));
+    RT_TRY(tmp.get(posL, size_t(n) + 1));
+    RT_TRY(tmp.get(posR, size_t(n) + 1));
+    RT_TRY(tmp.get(more, size_t(n)));
+    RT_TRY(tmp.get(flags, size_t(n) + 1));
+    RT_TRY(tmp.get(scan, size_t(n) + 1));
+    RT_TRY(tmp.get(segs[0], maxSegs));
+    RT_TRY(tmp.get(segs[1], maxSegs));
+    RT_TRY(tmp.get(segOut, maxSegs));
+    RT_TRY(tmp.get(blocks, size_t(n)));
+    RT_TRY(tmp.get(heaps, size_t(TABLE_LEVELS) * MAX_HEAP_PARTS));
+    RT_TRY(tmp.get(ctl, 1));
+    RT_TRY(hipMemsetAsync(ctl, 0, sizeof(Ctl), nullptr));
+    RT_TRY(hipMemsetAsync(flags + n, 0, sizeof(unsigned long long), nullptr));
+    size_t scanBytes = 0;
+    RT_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, flags, scan, n + 1, nullptr));
+    char* scanTemp;
+    RT_TRY(tmp.get(scanTemp, scanBytes));
+    const dim3 block(256), grid(uint32_t((size_t(n) + 255) / 256));
+    hipLaunchKernelGGL(k_prim_bounds, grid, block, 0, nullptr, geo, n, dLo, dHi, dCentroid, a, ctl);
+    // ---- the sorts, level by level
+    int cur = 0;
+    Ctl host;
+    for (int level = 0; level < T.depth; level++) {
+        const int maxCount = T.cLo[level] + 1;
+        const int nActive = maxCount > SORT_THRESHOLD ? (1 << level) : 0; // (then every node of the level exists)
+        if (size_t(nActive) > maxSegs) return hipErrorInvalidValue;       // cannot happen: 2^level parts of more than 16
+        hipLaunchKernelGGL(k_level_init, grid, block, 0, nullptr, a, dCentroid, segOf, segs[cur], blocks, ctl, n, level, cur, nActive);
+        if (nActive > 0) {
+            // introsort needs about 1.4 log2(count / 16) partitions of a part; the rounds are launched in batches and the
+            // number of parts still active is read back after each
+            int batch = 2;
+            for (int c = maxCount; c > SORT_THRESHOLD; c >>= 1) batch += (batch & 1) ? 2 : 1;
+            while (true) {
+                for (int r = 0; r < batch; r++) {
+                    hipLaunchKernelGGL(k_round_flags, grid, block, 0, nullptr, a, segOf, segs[cur], flags, ctl, n, cur);
+                    RT_TRY(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, flags, scan, n + 1, nullptr));
+                    hipLaunchKernelGGL(k_round_ranks, grid, block, 0, nullptr, a, segOf, segs[cur], scan, posL, posR, ctl, n, cur);
+                    hipLaunchKernelGGL(k_round_cuts, dim3(uint32_t((maxSegs + 255) / 256)), block, 0, nullptr, segs[cur], segs[cur ^ 1], segOut, scan, posL, posR, blocks, heaps, ctl, level, cur);
+                    hipLaunchKernelGGL(k_round_swaps, grid, block, 0, nullptr, a, segOf, segs[cur], segOut, scan, posR, ctl, n, cur);
+                    cur ^= 1;
+                }
+                RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+                RT_TRY(hipStreamSynchronize(nullptr));
+                if (host.flags) return hipSuccess; // unsupported: a NaN key, or too much for the heapsort kernel
+                if (host.nActive[cur] == 0) break;
+                batch = 3;
+            }
+            hipLaunchKernelGGL(k_heap_sorts, dim3(MAX_HEAP_PARTS / 256), block, 0, nullptr, a, heaps, ctl, level);
+        }
+        hipLaunchKernelGGL(k_sort_blocks, grid, block, 0, nullptr, a, blocks, ctl, level);
+    }
+    RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    RT_TRY(hipStreamSynchronize(nullptr));
+    if (host.flags) return hipSuccess;
+    // ---- nodes, boxes, device tables
+    out.numRefNodes = size_t(T.sub[0][n - T.cLo[0]]);
+    out.numInner = size_t(T.inner[0][n - T.cLo[0]]);
+    out.numLeaves = T.leaves[0][n - T.cLo[0]];
+    out.numLevels = T.depth + 1;
+    out.numPrims = size_t(n);
+    struct Guard {
+        DeviceBvh& d;
+        bool keep = false;
+        ~Guard() { if (!keep) d.release(); }
+    } guard { out };
+    RT_TRY(own(out.nodes, out.numInner));
+    RT_TRY(own(out.prims, out.numPrims));
+    RT_TRY(own(out.attrs, out.numPrims));
+    RT_TRY(own(out.primOrder, out.numPrims));
+    RT_TRY(own(out.refNodes, out.numRefNodes));
+    RT_TRY(own(out.refPrims, out.numPrims));
+    const unsigned long long heap = (2ull << T.depth) - 1ull; // threads of the per-node kernels: every (level, path)
+    const dim3 gridNodes(uint32_t((heap + 255) / 256));
+    hipLaunchKernelGGL(k_nodes, gridNodes, block, 0, nullptr, T, a, dLo, dHi, out.refNodes, more);
+    for (int level = T.depth - 1; level >= 0; level--)
+        hipLaunchKernelGGL(k_boxes, dim3(uint32_t(((1ull << level) + 255) / 256)), block, 0, nullptr, T, level, out.refNodes);
+    hipLaunchKernelGGL(k_flatten, gridNodes, block, 0, nullptr, T, out.refNodes, out.nodes);
+    hipLaunchKernelGGL(k_prim_records, grid, block, 0, nullptr, geo, n, a, more, out.prims, out.attrs, out.refPrims, out.primOrder);
+    RT_TRY(hipGetLastError());
+    rt_node_record root;
+    RT_TRY(hipMemcpyAsync(&root, out.refNodes, sizeof root, hipMemcpyDeviceToHost, nullptr));
+    RT_TRY(hipStreamSynchronize(nullptr));
 #undef RT_TRY
+    std::memcpy(out.rootLo, root.lower, 12);
+    std::memcpy(out.rootHi, root.upper, 12);
+    out.rootRef = root.is_leaf ? ~root.a : 0;
+    guard.keep = true;
+    unsupported = false;
     return hipSuccess;
 }
 

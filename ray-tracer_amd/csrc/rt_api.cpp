@@ -59,6 +59,15 @@ struct DevBuf {
         ptr = nullptr;
         cap = 0;
     }
+    // takes over a hipMalloc'd block
+    template <class T>
+    void adopt(T*& p, size_t bytes)
+    {
+        release();
+        ptr = p;
+        cap = bytes;
+        p = nullptr;
+    }
 };
 
 template <class T>
@@ -157,8 +166,10 @@ struct rt_bvh {
     HostBvh host;
     FlatBvh flat; // host image of the device tables; dropped after the upload
     bool uploaded = false;
-    bool deviceSorted = false; // the per-level sorts of the build ran on the GPU
-    DevBuf nodes, prims, attrs, primOrder;
+    bool deviceBuilt = false; // built by rt_bvh_build_device on the GPU: `host` holds the counts only, the node and
+                              // primitive lists stay in device memory (refNodes / refPrims) until rt_bvh_export asks
+    DevBuf nodes, prims, attrs, primOrder, refNodes, refPrims;
+    size_t numRefNodes = 0, numRefPrims = 0;
     SceneView view {};
     // `lock` guards the upload and the buffers of the batch entry points (those calls run one at a time)
     std::mutex lock;
@@ -310,6 +321,33 @@ rt_status upload_scene(rt_scene* s)
     return RT_OK;
 }
 
+// The kernels' view of a hierarchy whose tables are in device memory.
+void fill_view(rt_bvh* b, const float* rootLo, const float* rootHi, int32_t rootRef, size_t numPrims, size_t numNodes)
+{
+    rt_scene* scene = b->scene;
+    SceneView& v = b->view;
+    v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
+    v.prims = static_cast<const PrimRec*>(b->prims.ptr);
+    v.attrs = static_cast<const AttrRec*>(b->attrs.ptr);
+    v.mats = static_cast<const MaterialRec*>(scene->mats.ptr);
+    v.texels = static_cast<const uint8_t*>(scene->texels.ptr);
+    v.textures = static_cast<const ImageRec*>(scene->textures.ptr);
+    v.primOrder = static_cast<const uint32_t*>(b->primOrder.ptr);
+    std::memcpy(v.skybox, scene->skybox, sizeof v.skybox);
+    std::memcpy(v.rootLo, rootLo, 12);
+    std::memcpy(v.rootHi, rootHi, 12);
+    v.rootRef = rootRef;
+    v.numPrims = int32_t(numPrims);
+    v.numNodes = int32_t(numNodes);
+    v.numMeshes = int32_t(scene->host.meshes.size());
+    v.hasSkybox = scene->host.skybox.size() == 6;
+    v.hasSpheres = !scene->host.spheres.empty();
+    v.stackDepth = b->host.numLevels;
+    v.bounded = 1;
+    for (int i = 0; i < 3; i++)
+        if (!(std::fabs(v.rootLo[i]) <= 1e30f && std::fabs(v.rootHi[i]) <= 1e30f)) v.bounded = 0;
+}
+
 // Makes the device tables of `b` (and of its scene) exist.  Caller holds b->lock.
 rt_status upload_bvh(rt_bvh* b)
 {
@@ -323,27 +361,7 @@ rt_status upload_bvh(rt_bvh* b)
     RT_HIP(upload(b->prims, flat.prims));
     RT_HIP(upload(b->attrs, flat.attrs));
     RT_HIP(upload(b->primOrder, flat.primOrder));
-    SceneView& v = b->view;
-    v.nodes = static_cast<const NodeRec*>(b->nodes.ptr);
-    v.prims = static_cast<const PrimRec*>(b->prims.ptr);
-    v.attrs = static_cast<const AttrRec*>(b->attrs.ptr);
-    v.mats = static_cast<const MaterialRec*>(scene->mats.ptr);
-    v.texels = static_cast<const uint8_t*>(scene->texels.ptr);
-    v.textures = static_cast<const ImageRec*>(scene->textures.ptr);
-    v.primOrder = static_cast<const uint32_t*>(b->primOrder.ptr);
-    std::memcpy(v.skybox, scene->skybox, sizeof v.skybox);
-    std::memcpy(v.rootLo, flat.rootLo, 12);
-    std::memcpy(v.rootHi, flat.rootHi, 12);
-    v.rootRef = flat.rootRef;
-    v.numPrims = int32_t(flat.prims.size());
-    v.numNodes = int32_t(flat.nodes.size());
-    v.numMeshes = int32_t(scene->host.meshes.size());
-    v.hasSkybox = scene->host.skybox.size() == 6;
-    v.hasSpheres = !scene->host.spheres.empty();
-    v.stackDepth = b->host.numLevels;
-    v.bounded = 1;
-    for (int i = 0; i < 3; i++)
-        if (!(std::fabs(v.rootLo[i]) <= 1e30f && std::fabs(v.rootHi[i]) <= 1e30f)) v.bounded = 0;
+    fill_view(b, flat.rootLo, flat.rootHi, flat.rootRef, flat.prims.size(), flat.nodes.size());
     b->flat = FlatBvh {};
     b->uploaded = true;
     return RT_OK;
@@ -531,59 +549,74 @@ rt_status rt_bvh_build_device(rt_scene* scene, const rt_bvh_options* options, rt
     if (!scene || !out) return fail(RT_ERR_INVALID, "rt_bvh_build_device: null argument");
     rt_bvh_options opt { 0, 32, 64 };
     if (options) opt = *options;
-    std::vector<int> order;
-    bool useOrder = false;
+    if (opt.max_level < 0 || opt.max_level > RT_MAX_LEVELS - 1) return fail(RT_ERR_LIMIT, "max_level must be in [0, 32]");
+    // the scene's own tables first: that also fixes the device the scene (and this hierarchy) lives on
+    rt_status st = upload_scene(scene);
+    if (st != RT_OK) return st;
+    RT_HIP(hipSetDevice(scene->device));
+    DeviceBvh dev;
+    bool unsupported = true;
     try {
-        if (device_sort_applies(scene->host, opt)) {
-            std::vector<float> centroids;
-            primitive_centroids(scene->host, centroids);
-            bool ambiguous = false;
-            RT_HIP(device_split_order(centroids.data(), centroids.size() / 3, order, ambiguous, nullptr));
-            useOrder = !ambiguous;
+        const hipError_t e = device_build(scene->host, opt, dev, unsupported);
+        if (e != hipSuccess) {
+            dev.release();
+            return hip_fail(e, "rt_bvh_build_device");
         }
     } catch (const std::exception& e) {
+        dev.release();
         return fail(RT_ERR_LIMIT, std::string("rt_bvh_build_device: ") + e.what());
     }
-    if (!useOrder) return rt_bvh_build(scene, options, out);
+    if (unsupported) return rt_bvh_build(scene, options, out);
     *out = nullptr;
-    if (opt.max_level < 0 || opt.max_level > RT_MAX_LEVELS - 1) return fail(RT_ERR_LIMIT, "max_level must be in [0, 32]");
     rt_bvh* b = new (std::nothrow) rt_bvh;
-    if (!b) return fail(RT_ERR_INVALID, "out of host memory");
-    b->scene = scene;
-    b->deviceSorted = true;
-    try {
-        build_bvh(scene->host, opt, b->host, &order);
-        flatten_bvh(scene->host, b->host, b->flat);
-    } catch (const std::exception& e) {
-        delete b;
-        return fail(RT_ERR_LIMIT, std::string("rt_bvh_build_device: ") + e.what());
-    } catch (...) {
-        delete b;
-        return fail(RT_ERR_LIMIT, "rt_bvh_build_device: unknown failure");
+    if (!b) {
+        dev.release();
+        return fail(RT_ERR_INVALID, "out of host memory");
     }
+    b->scene = scene;
+    b->deviceBuilt = true;
+    b->host.numLevels = dev.numLevels;
+    b->host.numLeaves = dev.numLeaves;
+    b->numRefNodes = dev.numRefNodes;
+    b->numRefPrims = dev.numPrims;
+    b->nodes.adopt(dev.nodes, dev.numInner * sizeof(NodeRec));
+    b->prims.adopt(dev.prims, dev.numPrims * sizeof(PrimRec));
+    b->attrs.adopt(dev.attrs, dev.numPrims * sizeof(AttrRec));
+    b->primOrder.adopt(dev.primOrder, dev.numPrims * sizeof(uint32_t));
+    b->refNodes.adopt(dev.refNodes, dev.numRefNodes * sizeof(rt_node_record));
+    b->refPrims.adopt(dev.refPrims, dev.numPrims * sizeof(rt_prim_ref));
+    fill_view(b, dev.rootLo, dev.rootHi, dev.rootRef, dev.numPrims, dev.numInner);
+    b->uploaded = true;
     *out = b;
     return RT_OK;
 }
 
-int32_t rt_bvh_device_sorted(const rt_bvh* b) { return b && b->deviceSorted ? 1 : 0; }
+int32_t rt_bvh_device_sorted(const rt_bvh* b) { return b && b->deviceBuilt ? 1 : 0; }
 
 void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
     b->pool.clear(); // (waits for whatever a call left queued on a set)
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->rays, &b->hits, &b->misc }) d->release();
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->refNodes, &b->refPrims, &b->rays, &b->hits, &b->misc }) d->release();
     delete b;
 }
 
 int32_t rt_bvh_num_levels(const rt_bvh* b) { return b ? b->host.numLevels : 0; }
 int32_t rt_bvh_num_leaves(const rt_bvh* b) { return b ? b->host.numLeaves : 0; }
-int32_t rt_bvh_num_nodes(const rt_bvh* b) { return b ? int32_t(b->host.nodes.size()) : 0; }
-int32_t rt_bvh_num_prim_refs(const rt_bvh* b) { return b ? int32_t(b->host.prims.size()) : 0; }
+int32_t rt_bvh_num_nodes(const rt_bvh* b) { return b ? int32_t(b->deviceBuilt ? b->numRefNodes : b->host.nodes.size()) : 0; }
+int32_t rt_bvh_num_prim_refs(const rt_bvh* b) { return b ? int32_t(b->deviceBuilt ? b->numRefPrims : b->host.prims.size()) : 0; }
 
 rt_status rt_bvh_export(const rt_bvh* b, rt_node_record* nodes, int32_t nNodes, rt_prim_ref* prims, int32_t nPrims)
 {
     if (!b) return fail(RT_ERR_INVALID, "rt_bvh_export: null bvh");
-    if (nNodes < int32_t(b->host.nodes.size()) || nPrims < int32_t(b->host.prims.size())) return fail(RT_ERR_INVALID, "rt_bvh_export: output arrays too small");
+    if (nNodes < rt_bvh_num_nodes(b) || nPrims < rt_bvh_num_prim_refs(b)) return fail(RT_ERR_INVALID, "rt_bvh_export: output arrays too small");
+    if (b->deviceBuilt) {
+        // a hierarchy built on the GPU keeps these lists there
+        RT_HIP(hipSetDevice(b->scene->device));
+        if (nodes) RT_HIP(hipMemcpy(nodes, b->refNodes.ptr, b->numRefNodes * sizeof(rt_node_record), hipMemcpyDeviceToHost));
+        if (prims) RT_HIP(hipMemcpy(prims, b->refPrims.ptr, b->numRefPrims * sizeof(rt_prim_ref), hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
     if (nodes) std::memcpy(nodes, b->host.nodes.data(), b->host.nodes.size() * sizeof(rt_node_record));
     if (prims) std::memcpy(prims, b->host.prims.data(), b->host.prims.size() * sizeof(rt_prim_ref));
     return RT_OK;

@@ -41,6 +41,11 @@ RT_HD vec3 reflect(vec3 I, vec3 N) { return I - N * dot(N, I) * 2.0f; }
 // glm::max / glm::min are plain comparisons (their NaN behaviour differs from fmaxf/fminf)
 RT_HD float sel_max(float a, float b) { return (a < b) ? b : a; }
 RT_HD float sel_min(float a, float b) { return (b < a) ? b : a; }
+// std::fmin / std::fmax of the hierarchy build (reference src/bounding_volume_hierarchy.cpp:21-31), spelled out so that
+// host and device builders agree on signed zeros: the first argument unless the second is strictly smaller / larger (the
+// sign of a zero bound never changes a ray/box decision); a NaN first argument yields the second.
+RT_HD float min_first(float x, float y) { return x != x ? y : (y < x ? y : x); }
+RT_HD float max_first(float x, float y) { return x != x ? y : (y > x ? y : x); }
 // reference src/intersect.cpp:17-20
 RT_HD bool is_zero(float a) { return fabsf(a) <= 0.000001f; }
 RT_HD float comp(vec3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }

@@ -201,6 +201,9 @@ BvhInterface::BvhInterface(Scene* pScene, const Features& features)
         return;
     }
     rt_bvh_options opt { features.extra.enableBvhSahBinning ? 1 : 0, extr_max_level, extr_sah_bins };
+    // built on the calling thread's current GPU (same tree, tens of times faster on large meshes); without a usable GPU,
+    // on the host (the tables are then uploaded by the first call that renders)
+    if (rt_bvh_build_device(m_scene, &opt, &m_bvh) == RT_OK) return;
     if (rt_bvh_build(m_scene, &opt, &m_bvh) != RT_OK) std::fprintf(stderr, "BvhInterface: %s\n", rt_last_error());
 }
 
