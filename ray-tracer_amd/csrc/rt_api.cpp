@@ -132,10 +132,14 @@ struct RenderScratch {
     hipEvent_t done = nullptr;
     hipStream_t lastStream = nullptr;
     bool pending = false, busy = false;
+    // pinned host memory the wavefront passes' device-side bookkeeping reports to (node count, overflow flag, table)
+    unsigned long long* wfReport = nullptr;
 
     hipError_t init()
     {
         hipError_t e;
+        if ((e = hipHostMalloc(reinterpret_cast<void**>(&wfReport), (2 + Q_COUNT - Q_WF_GEN) * sizeof(unsigned long long), hipHostMallocDefault)) != hipSuccess) return e;
+        std::memset(wfReport, 0, (2 + Q_COUNT - Q_WF_GEN) * sizeof(unsigned long long));
         for (hipEvent_t* ev : { &evStart, &evMid, &evStop, &evSplit[0], &evSplit[1], &evSplit[2], &evSplit[3], &evShadowB[0], &evShadowB[1] })
             if ((e = hipEventCreate(ev)) != hipSuccess) return e;
         for (hipEvent_t* ev : { &evFork, &evJoin, &done })
@@ -154,6 +158,7 @@ struct RenderScratch {
             (void)hipStreamSynchronize(ownStream);
             (void)hipStreamDestroy(ownStream);
         }
+        if (wfReport) (void)hipHostFree(wfReport);
         for (DevBuf* d : { &stats, &frame, &queue, &queueCounters, &visibility, &shadowQueue, &pairSpill, &samples, &dofFlags, &wfRays, &wfNodes, &wfMeta, &wfValue, &wfHits, &wfHitNode, &wfGlossy, &gaveUpQueue, &pairSpillAux })
             d->release();
         for (hipEvent_t ev : { evStart, evMid, evStop, evSplit[0], evSplit[1], evSplit[2], evSplit[3], evShadowB[0], evShadowB[1], evFork, evJoin, done })
@@ -927,6 +932,7 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             P.wfGlossy = static_cast<WfGlossy*>(w->wfGlossy.ptr);
             P.wfCapacity = uint32_t(nodes);
             P.wfGlossyCapacity = uint32_t(calls);
+            P.wfReport = w->wfReport;
             if (cap < 2 * nodes) cap = 2 * nodes;
         }
         const size_t items = cap * perHit;
@@ -974,10 +980,11 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         dOut = static_cast<float*>(w->frame.ptr);
     }
     P.out = dOut;
-    RT_HIP(w->stats.reserve(STAT_COUNT * sizeof(unsigned long long)));
+    // three blocks of counters: the call's, those of a wavefront chunk not yet known to stand, a copy kept across a pass
+    RT_HIP(w->stats.reserve(3 * STAT_COUNT * sizeof(unsigned long long)));
     P.stats = static_cast<unsigned long long*>(w->stats.ptr);
     P.countTests = stats != nullptr && params->count_tests != 0;
-    RT_HIP(hipMemsetAsync(w->stats.ptr, 0, STAT_COUNT * sizeof(unsigned long long), s));
+    RT_HIP(hipMemsetAsync(w->stats.ptr, 0, 3 * STAT_COUNT * sizeof(unsigned long long), s));
     // a synchronous wait is only needed when the caller wants numbers or host pixels back
     const bool wait = stats != nullptr || !devicePtr;
     if (stats) RT_HIP(hipEventRecord(w->evStart, s));

@@ -125,7 +125,10 @@ struct FrameParams {
     WfGlossy* wfGlossy;    // glossy calls of the current generation
     uint32_t wfCapacity;   // nodes
     uint32_t wfGlossyCapacity;
-    uint32_t wfBegin, wfEnd; // node range of the generation a kernel works on
+    uint32_t wfBegin, wfEnd; // node range of the generation a kernel works on ...
+    int32_t wfGen;           // ... or, when >= 0, the generation whose range [table[wfGen], table[wfGen + 1]) the kernel reads
+                             // from the generation table on the device (Q_WF_GEN): the host does not know it yet
+    unsigned long long* wfReport; // pinned host memory the device reports a chunk's node count, overflow flag and table to
     uint32_t wfRootBegin;    // work id of the chunk's first root
     int32_t wfLighting;      // the queue passes read their rays from the nodes and write Lo there
     int32_t wfRootsTurn;     // k_wf_combine: evaluate the pixel samples' own nodes (else: every other node)
@@ -146,8 +149,10 @@ enum {
     Q_RANGE_BEGIN = Q_WF_OVERFLOW + 16, // lighting passes (cull / shadow / shade): the hit-queue entries they work on,
     Q_RANGE_END = Q_RANGE_BEGIN + 16,   // set by k_range once the entries exist
     Q_SHADOW_XCD = Q_RANGE_END + 16,    // 8 cursors (one per 128-byte line): shadow packets handed out per eighth of the queue
-    Q_COUNT = Q_SHADOW_XCD + 8 * 16
+    Q_WF_GEN = Q_SHADOW_XCD + 8 * 16,   // wavefront: generation table, entry g = nodes allocated when generation g's trace began
+    Q_COUNT = Q_WF_GEN + 64
 };
+enum { WF_MAX_GENERATIONS = 60 };        // (the table's size; ray_depth <= 8 and at most 24 see-through continuations)
 
 struct Counts {
     uint32_t primary = 0, shadow = 0, bounce = 0, probe = 0, box = 0, tri = 0, overflow = 0;

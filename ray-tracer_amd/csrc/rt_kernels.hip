@@ -1103,12 +1103,15 @@ __global__ void __launch_bounds__(WAVE) k_wf_trace(const FrameParams P)
     Counts cnt;
     const int lane = int(threadIdx.x);
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
-    const uint32_t n = P.wfEnd - P.wfBegin;
+    // the generation's node range: known to the host (roots; test paths) or read from the table the device keeps
+    const uint32_t begin = (!ROOTS && P.wfGen >= 0) ? uint32_t(P.queueCounters[Q_WF_GEN + P.wfGen]) : P.wfBegin;
+    const uint32_t end = (!ROOTS && P.wfGen >= 0) ? uint32_t(P.queueCounters[Q_WF_GEN + P.wfGen + 1]) : P.wfEnd;
+    const uint32_t n = end - begin;
     const uint32_t rounded = (n + 63u) & ~63u; // whole waves stay in the loop together
     const bool reflMap = P.f.environment_mapping && P.p.enabled_refl_map;
     const uint32_t filter = uint32_t(P.p.glossy_filter_size);
     for (uint32_t i = blockIdx.x * WAVE + threadIdx.x; i < rounded; i += gridDim.x * WAVE) {
-        uint32_t node = P.wfBegin + i; // ROOTS: assigned below, and only if the sample's call has children
+        uint32_t node = begin + i; // ROOTS: assigned below, and only if the sample's call has children
         uint32_t kind = WF_DEAD, nChildren = 0, depth = 0, blendDepth = 0, randBase = 0;
         bool pending = false, wantsLo = false;
         RayD r = make_ray(splat3(0.0f), splat3(1.0f));
@@ -1120,7 +1123,7 @@ __global__ void __launch_bounds__(WAVE) k_wf_trace(const FrameParams P)
         int sidx = 0;
         if (i < n) {
             if (ROOTS) {
-                work = P.wfRootBegin + P.wfBegin + i;
+                work = P.wfRootBegin + begin + i;
                 int x, y;
                 wf_pixel(P, work, nPix, pix, sidx, x, y);
                 // depth of field: the lens rays of a pixel exist only when its centre ray (an earlier pass) said so
@@ -1296,6 +1299,41 @@ __global__ void __launch_bounds__(WAVE) k_wf_trace(const FrameParams P)
         }
     }
     flush_counts(cnt, P.stats);
+}
+
+// Closes generation `gen` of a chunk on the device (gen 0 = the camera rays), so that the next one can be launched
+// without the host knowing how many calls it has.  The generation table T (Q_WF_GEN) holds the node count at every
+// generation boundary: T[0] = 0, generation g >= 1 traces the nodes [T[g - 1], T[g]) and this kernel, launched behind
+// its trace and sample generation, sets T[g + 1] to the nodes allocated so far.  After an overflow the following
+// generations are left empty.  The list of glossy calls starts again, and the host's copy of the chunk's state (pinned
+// memory, read after the one wait per chunk) is brought up to date.
+__global__ void k_wf_next(const FrameParams P, int gen)
+{
+    unsigned long long* c = P.queueCounters;
+    const unsigned long long nodes = c[Q_WF_NODES];
+    const bool overflow = c[Q_WF_OVERFLOW] != 0ull;
+    const unsigned long long now = overflow ? c[Q_WF_GEN + gen] : (nodes < (unsigned long long)P.wfCapacity ? nodes : (unsigned long long)P.wfCapacity);
+    c[Q_WF_GEN + gen + 1] = now;
+    c[Q_WF_GLOSSY] = 0ull;
+    if (P.wfReport) {
+        P.wfReport[0] = nodes;
+        P.wfReport[1] = overflow ? 1ull : 0ull;
+        P.wfReport[2 + gen + 1] = now;
+    }
+}
+
+// dst = src (add = 0) or dst += src, src = 0 (add = 1): the ray counters of a chunk are kept apart until the chunk is
+// known to stand, and the counters before a pass are kept in case the pass is rendered again another way
+__global__ void k_stats(unsigned long long* dst, unsigned long long* src, int add)
+{
+    const int i = int(threadIdx.x);
+    if (i >= STAT_COUNT) return;
+    if (add) {
+        dst[i] += src[i];
+        src[i] = 0ull;
+    } else {
+        dst[i] = src[i];
+    }
 }
 
 // One lane per (glossy call of the generation, sample): the perturbed reflection ray of reference src/gloss.cpp:14-51,
@@ -1625,72 +1663,94 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
 // Renders the pixel samples [sBegin, sEnd) of the call's rows as wavefront passes, in chunks of roots sized so that
 // the call trees of a chunk fit the node buffer.  A chunk that turns out not to fit (the fan-out of glossy calls is
 // only known once they are traced) is abandoned and rendered again as smaller chunks; what a node computes does not
-// depend on the chunking.  The generation loop needs the node count of each generation on the host, so this path
-// waits on the stream once per generation.
+// depend on the chunking.
+// The generations of a chunk are launched without the host knowing their sizes: every trace kernel reads its node range
+// from the generation table on the device (k_wf_next) and runs on a resident-size grid.  The host launches as many
+// generations as the previous chunk needed, then waits ONCE per chunk and reads, from pinned memory, the table and the
+// overflow flag — which it needs to size the value passes and to decide whether the chunk stands; if the tree turns out
+// deeper than launched, it launches two more generations and waits again.  The ray counters of a chunk go to a block of
+// their own (P.stats + STAT_COUNT) and are added to the call's only when the chunk stands.
 template <bool PRUNE>
 hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipStream_t stream, unsigned long long& nodesEvaluated)
 {
+    static_assert(STAT_COUNT <= 64, "k_stats runs one wave");
     hipError_t e;
+    if (!P.wfReport) return hipErrorInvalidValue;
+    P.wfReport[2] = 0ull; // T[0]
     P.sampleBegin = sBegin;
     P.sampleEnd = sEnd;
     const unsigned long long totalRoots = (unsigned long long)P.rowsLocal * (unsigned long long)P.width * (unsigned long long)(sEnd - sBegin);
     unsigned long long chunk = P.wfCapacity; // (the hit queue holds an entry per root and per node)
     if (chunk < 1) chunk = 1;
     unsigned long long done = 0;
-    unsigned long long host[Q_COUNT - Q_WF_NODES];
-    unsigned long long statsBackup[STAT_COUNT];
+    unsigned long long* const callStats = P.stats;
+    unsigned long long* const chunkStats = P.stats ? P.stats + STAT_COUNT : nullptr;
+    struct RestoreStats {
+        FrameParams& P;
+        unsigned long long* stats;
+        ~RestoreStats() { P.stats = stats; }
+    } restore { P, callStats };
+    P.stats = chunkStats;
+    // the deepest tree the features allow: a specular bounce per unit of ray_depth, and see-through continuations
+    int maxGenerations = 1 + ((P.f.recursive || P.f.glossy) ? P.p.ray_depth : 0) + (P.f.transparency ? P.p.max_transparency_depth : 0);
+    if (maxGenerations > WF_MAX_GENERATIONS) maxGenerations = WF_MAX_GENERATIONS;
+    static thread_local int generationsHint = 3; // generations the last chunk needed beyond its camera rays
     std::vector<uint32_t> gens;
+    const uint32_t capTrace = P.countTests ? resident_blocks(k_wf_trace<PRUNE, true, false>, WAVE, lds) : resident_blocks(k_wf_trace<PRUNE, false, false>, WAVE, lds);
     while (done < totalRoots) {
         const uint32_t nRoots = uint32_t(totalRoots - done < chunk ? totalRoots - done : chunk);
         if ((e = hipMemsetAsync(P.queueCounters, 0, Q_COUNT * sizeof(unsigned long long), stream)) != hipSuccess) return e;
-        // the ray counters of an abandoned chunk must not stay in the statistics
-        if (P.stats && (e = hipMemcpyAsync(statsBackup, P.stats, sizeof statsBackup, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; // (the two host buffers above are reused)
+        if (chunkStats && (e = hipMemsetAsync(chunkStats, 0, STAT_COUNT * sizeof(unsigned long long), stream)) != hipSuccess) return e;
         P.wfRootBegin = uint32_t(done);
         P.wfBegin = 0;
         P.wfEnd = nRoots;
+        P.wfGen = -1;
         P.wfLighting = 0;
         P.wfRootsTurn = 0;
-        gens.clear();
-        gens.push_back(0);
-        bool overflow = false;
-        bool roots = true;
-        while (true) {
-            const uint32_t n = P.wfEnd - P.wfBegin;
-            const uint32_t waves = (n + WAVE - 1) / WAVE;
-            uint32_t cap;
-            if (roots) cap = P.countTests ? resident_blocks(k_wf_trace<PRUNE, true, true>, WAVE, lds) : resident_blocks(k_wf_trace<PRUNE, false, true>, WAVE, lds);
-            else cap = P.countTests ? resident_blocks(k_wf_trace<PRUNE, true, false>, WAVE, lds) : resident_blocks(k_wf_trace<PRUNE, false, false>, WAVE, lds);
+        {
+            const uint32_t waves = (nRoots + WAVE - 1) / WAVE;
+            const uint32_t cap = P.countTests ? resident_blocks(k_wf_trace<PRUNE, true, true>, WAVE, lds) : resident_blocks(k_wf_trace<PRUNE, false, true>, WAVE, lds);
             const dim3 grid(waves < cap ? waves : cap);
-            if (roots) {
-                if (P.countTests) hipLaunchKernelGGL((k_wf_trace<PRUNE, true, true>), grid, dim3(WAVE), lds, stream, P);
-                else hipLaunchKernelGGL((k_wf_trace<PRUNE, false, true>), grid, dim3(WAVE), lds, stream, P);
-            } else {
-                if (P.countTests) hipLaunchKernelGGL((k_wf_trace<PRUNE, true, false>), grid, dim3(WAVE), lds, stream, P);
-                else hipLaunchKernelGGL((k_wf_trace<PRUNE, false, false>), grid, dim3(WAVE), lds, stream, P);
-            }
+            if (P.countTests) hipLaunchKernelGGL((k_wf_trace<PRUNE, true, true>), grid, dim3(WAVE), lds, stream, P);
+            else hipLaunchKernelGGL((k_wf_trace<PRUNE, false, true>), grid, dim3(WAVE), lds, stream, P);
             if (P.f.glossy) hipLaunchKernelGGL(k_wf_spawn, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
-            if ((e = hipMemcpyAsync(host, &P.queueCounters[Q_WF_NODES], sizeof host, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-            if (host[Q_WF_OVERFLOW - Q_WF_NODES] != 0) {
+            hipLaunchKernelGGL(k_wf_next, dim3(1), dim3(1), 0, stream, P, 0);
+        }
+        // generations 1 .. : launched ahead, sized on the device
+        int launched = 0, wanted = generationsHint < 1 ? 1 : generationsHint;
+        bool overflow = false;
+        int complete = -1; // first generation that made no call
+        while (true) {
+            if (wanted > maxGenerations) wanted = maxGenerations;
+            for (; launched < wanted; launched++) {
+                P.wfGen = launched; // generation launched + 1 traces [T[launched], T[launched + 1])
+                if (P.countTests) hipLaunchKernelGGL((k_wf_trace<PRUNE, true, false>), dim3(capTrace), dim3(WAVE), lds, stream, P);
+                else hipLaunchKernelGGL((k_wf_trace<PRUNE, false, false>), dim3(capTrace), dim3(WAVE), lds, stream, P);
+                if (P.f.glossy) hipLaunchKernelGGL(k_wf_spawn, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+                hipLaunchKernelGGL(k_wf_next, dim3(1), dim3(1), 0, stream, P, launched + 1);
+            }
+            P.wfGen = -1;
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e; // the one wait of the chunk
+            const volatile unsigned long long* report = P.wfReport;
+            if (report[1] != 0ull) {
                 overflow = true;
                 break;
             }
-            const uint32_t nodes = uint32_t(host[0]);
-            if (nodes == gens.back()) break; // no call of this generation made another
-            if ((e = hipMemsetAsync(&P.queueCounters[Q_WF_GLOSSY], 0, sizeof(unsigned long long), stream)) != hipSuccess) return e;
-            P.wfBegin = gens.back();
-            P.wfEnd = nodes;
-            gens.push_back(nodes);
-            roots = false;
+            for (int g = 0; g <= launched && complete < 0; g++)
+                if (report[2 + g + 1] == report[2 + g]) complete = g;
+            if (complete >= 0 || launched >= maxGenerations) break;
+            wanted = launched + 2;
         }
         if (overflow) {
             if (nRoots <= 1) return hipErrorOutOfMemory; // one pixel sample's call tree exceeds the node buffer
-            if (P.stats && (e = hipMemcpyAsync(P.stats, statsBackup, sizeof statsBackup, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
             chunk = nRoots / 2u;
-            continue;
+            continue; // (the chunk's ray counters are dropped with it)
         }
+        if (complete < 0) complete = launched; // (cannot happen: the features bound the tree's depth)
+        generationsHint = complete < 1 ? 1 : complete;
+        gens.clear();
+        for (int g = 0; g <= complete; g++) gens.push_back(uint32_t(P.wfReport[2 + g]));
         if (P.f.glossy && P.drawsPerHit > 0 && gens.size() > 1) {
             auto blocks_for = [](uint32_t n) { const uint32_t b = (n + BLOCK - 1) / BLOCK; return dim3(b < 256u * 16u ? b : 256u * 16u); };
             for (size_t g = gens.size() - 1; g-- > 0;) { // subtree totals, deepest generation first
@@ -1731,6 +1791,7 @@ hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipS
             }
         }
         P.wfRootsTurn = 0;
+        if (chunkStats) hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, callStats, chunkStats, 1);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         nodesEvaluated += (unsigned long long)nRoots + gens.back();
         done += nRoots;
@@ -1789,12 +1850,9 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
     bool wavefrontGaveUp = false;
     auto pass = [&](int sBegin, int sEnd) -> hipError_t {
         if (wavefront && !wavefrontGaveUp) {
-            // (the ray counters as they stand, in case the pass has to be done again)
-            unsigned long long before[STAT_COUNT];
-            if (P.stats) {
-                if ((e = hipMemcpyAsync(before, P.stats, sizeof before, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-                if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-            }
+            // (the ray counters as they stand are kept on the device, in case the pass has to be done again)
+            unsigned long long* const backup = P.stats ? P.stats + 2 * STAT_COUNT : nullptr;
+            if (backup) hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, backup, P.stats, 0);
             const unsigned long long nodesBefore = nodesEvaluated;
             e = prune ? wavefront_pass<true>(P, sBegin, sEnd, lds, stream, nodesEvaluated) : wavefront_pass<false>(P, sBegin, sEnd, lds, stream, nodesEvaluated);
             if (e != hipErrorOutOfMemory) return e;
@@ -1803,10 +1861,7 @@ hipError_t launch_render(const FrameParams& Pin, hipStream_t stream, hipEvent_t 
             // call and gives the same frame.  What the abandoned pass has written is written again.
             wavefrontGaveUp = true;
             nodesEvaluated = nodesBefore;
-            if (P.stats) {
-                if ((e = hipMemcpyAsync(P.stats, before, sizeof before, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
-                if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-            }
+            if (backup) hipLaunchKernelGGL(k_stats, dim3(1), dim3(64), 0, stream, P.stats, backup, 0);
         }
         P.sampleBegin = sBegin;
         P.sampleEnd = sEnd;
