@@ -889,16 +889,27 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             return e ? std::atol(e) : 0L;
         }();
         const bool bounce = features->recursive || features->glossy || features->transparency || (features->environment_mapping && params->enabled_refl_map);
-        // Which glossy frames gain from the wavefront passes (measured, 1920x1080, 36 spp, 64 samples per glossy call): where
-        // lighting casts shadow rays, or most surfaces are specular, the per-lane kernel loses (a lane traces a call's
-        // samples and their shadow rays one after the other: the dragon-class mesh under the area light took 170 s and
-        // more per quarter-size frame, 21 s in passes); where a fifth of the area is specular and no light casts shadows
-        // (Config 4: TransparentCornell 16.2 ms in passes, 14.9 ms per lane; TransparentCubes 9.8 / 9.0) it wins.
-        const bool glossyInPasses = features->glossy && (P.shadowSamplesPerHit > 0 || b->scene->specularShare > 0.5f);
-        if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && glossyInPasses))) {
-            // at most 24 Mi nodes (2 GB of node records), and no more than the hit queue may hold entries for: a chunk has
-            // at most `nodes` roots and `nodes` nodes, each with at most one hit entry
-            size_t nodeLimit = size_t(24) << 20;
+        // Glossy frames run as wavefront passes (measured, 1920x1080, 36 spp, 64 samples per glossy call, node buffer
+        // large enough for the frame to be one chunk: TransparentCornell 13.9 ms against 14.9 ms per lane, TransparentCubes
+        // 8.7 / 8.9; where lighting casts shadow rays or most surfaces are specular the per-lane kernel is out of the
+        // question: a lane traces a call's samples and their shadow rays one after the other, the dragon-class mesh under
+        // the area light took 170 s and more per quarter-size frame, 21 s in passes).
+        if (bounce && (wavefrontMode == 1 || (wavefrontMode < 0 && features->glossy))) {
+            // At most 96 Mi nodes (a 1080p frame at 36 samples per pixel is then a single chunk; about 130 bytes per node
+            // plus 10 per shadow-casting light sample, in node records, hit queue and shadow work items), no more than a
+            // sixth of the device memory that is free, and no more than the hit queue may hold entries for: a chunk has at
+            // most `nodes` roots and `nodes` nodes, each with at most one hit entry.
+            static const long nodeLimitMi = [] {
+                const char* e = std::getenv("RT_WAVEFRONT_NODE_LIMIT"); // Mi nodes
+                return e ? std::atol(e) : 96L;
+            }();
+            size_t nodeLimit = size_t(nodeLimitMi < 1 ? 1 : nodeLimitMi) << 20;
+            {
+                size_t freeBytes = 0, totalBytes = 0;
+                const size_t perNode = 132 + 10 * perHit;
+                if (w->wfRays.cap == 0 && hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && nodeLimit > freeBytes / 6 / perNode) nodeLimit = freeBytes / 6 / perNode;
+                if (nodeLimit < (size_t(1) << 20)) nodeLimit = size_t(1) << 20;
+            }
             if (nodeLimit > itemBudget / perHit / 2) nodeLimit = itemBudget / perHit / 2;
             size_t nodes = 4 * want;
             if (nodes < (size_t(1) << 20)) nodes = size_t(1) << 20;

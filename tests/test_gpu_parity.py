@@ -404,9 +404,8 @@ def test_wavefront_chunks_that_overflow_are_split():
 
 
 def test_wavefront_nodes_are_reported(lib):
-    """rt_stats.wavefront_nodes says which way a frame went.  Left to itself the library sends a glossy frame through the
-    wavefront passes when a light casts shadow rays or most of the scene's area is specular, and to the per-lane kernel
-    otherwise; a direct-lighting frame never takes the passes, a mirror frame only when forced."""
+    """rt_stats.wavefront_nodes says which way a frame went.  Left to itself the library sends every glossy frame through
+    the wavefront passes; a direct-lighting frame never takes them, a mirror frame only when forced."""
     g, sc, orc, sh, bvh = setup(lib, "transparent_cornell")
     lights, n = sc.light_array()
     W, H = 64, 40
@@ -416,9 +415,9 @@ def test_wavefront_nodes_are_reported(lib):
         assert st.wavefront_nodes == 0
     else:
         assert st.wavefront_nodes >= W * H and st.bounce_rays > 0
-    # no shadow rays and a fifth of the area specular: per lane unless forced
+    # no shadow rays and a fifth of the area specular: passes all the same
     _, st = lib.render(bvh, cam("A", (W, H)), lights, n, rt.features(shading=1, glossy=1, transparency=1), rt.default_params(glossy_filter_size=16), W, H)
-    assert (st.wavefront_nodes > 0) == (forced == "1")
+    assert (st.wavefront_nodes > 0) == (forced != "0")
     # everything specular (the monkey): passes unless switched off
     g2, sc2, orc2, sh2, bvh2 = setup(lib, "monkey")
     lights2, n2 = sc2.light_array()
