@@ -122,6 +122,11 @@ def main():
     gathered = tiling.gather_buffers(local, world) if (world > 1 and rank == 0) else None
     row_index = tiling.frame_row_index(world, HEIGHT, dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
+    # BENCH_GATHER=native: the blocks travel by the library's own grouped RCCL sends / receives (rt_gather_blocks)
+    # instead of torch.distributed's gather; needs a GPU per rank (RCCL refuses two ranks on one device)
+    native = world > 1 and os.environ.get("BENCH_GATHER") == "native" and not os.environ.get("BENCH_ONE_GPU_REHEARSAL")
+    comm = tiling.native_comm(lib, rank, world) if native else None
+    native_frame = torch.empty((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev) if (native and rank == 0) else None
 
     def render_frame(p):
         """Renders this rank's rows into `local`; returns the summed rt_stats of its rt_render calls."""
@@ -146,7 +151,10 @@ def main():
 
     def step():
         st = render_frame(params)
-        frame = tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered, row_index=row_index)
+        if native:
+            frame = tiling.gather_frame_native(lib, comm, local, rank, world, WIDTH, HEIGHT, frame=native_frame, stream=stream)
+        else:
+            frame = tiling.gather_frame(local, rank, world, WIDTH, HEIGHT, gathered=gathered, row_index=row_index)
         if rank == 0:
             if feats.bloom:  # the whole-frame post pass runs where the frame is assembled (reference src/render.cpp:125-127)
                 frame = frame.contiguous()

@@ -270,6 +270,36 @@ rt_status rt_bloom(float* pixels, int32_t width, int32_t height, const rt_params
 rt_status rt_bloom_static(float* device_pixels, int32_t width, int32_t height, const rt_params* params, void* stream);
 uint64_t rt_bloom_static_max_pixels(void);
 
+/* Multi-GPU frame assembly, one rank (process or host thread) per GPU.  Replaces the shared Screen that the reference's
+ * row threads write into (`#pragma omp parallel for` over y, src/render.cpp:86-89; the per-camera threads of
+ * src/main.cpp:533-552 when the work is dealt to GPUs): rank r of `world` renders rt_render_blocks(row_block, r, world)
+ * into device memory and rt_gather_blocks moves every block straight into its place in the root's device frame, as one
+ * group of RCCL sends / receives over xGMI (no pass through host memory; the root's own blocks are device copies).
+ * Bloom, which needs the whole frame, runs on the root afterwards (rt_bloom).
+ * RCCL is loaded at run time (RT_RCCL_LIBRARY, default librccl.so.1); without it these calls return RT_ERR_NO_DEVICE.
+ * A communicator belongs to the device that was current when it was made.  rt_comm_unique_id + rt_comm_init_rank
+ * bootstrap ranks in different processes (the id travels by any channel the caller has); rt_comm_init_all makes the
+ * communicators of n devices of one process. */
+typedef struct rt_comm rt_comm;
+#define RT_COMM_ID_BYTES 128
+rt_status rt_comm_unique_id(uint8_t* id /* RT_COMM_ID_BYTES */);
+rt_status rt_comm_init_rank(const uint8_t* id, int32_t rank, int32_t world, rt_comm** out);
+rt_status rt_comm_init_all(int32_t n, const int32_t* devices /* NULL: 0..n-1 */, rt_comm** out /* n handles */);
+void rt_comm_destroy(rt_comm* comm);
+int32_t rt_comm_rank(const rt_comm* comm);
+int32_t rt_comm_world(const rt_comm* comm);
+/* `share`: this rank's blocks as rt_render_blocks wrote them (device memory); `frame`: width x height float RGB in
+ * device memory on the root (ignored elsewhere).  Queued on `stream`; every rank of the communicator must call it. */
+rt_status rt_gather_blocks(rt_comm* comm, int32_t root, const float* share, float* frame, int32_t width, int32_t height,
+    int32_t row_block, void* stream);
+/* Both steps in one call, for callers without device memory of their own (the C++ facade): renders the blocks of this
+ * communicator's rank into a buffer the hierarchy keeps, gathers them, and on the root leaves the assembled frame in
+ * `frame` (host pointer when device_ptr == 0: one device-to-host copy of the whole frame instead of one per share).
+ * Returns when this rank's part is done.  `bvh` must live on the communicator's device. */
+rt_status rt_render_blocks_gather(const rt_bvh* bvh, const rt_camera* camera, const rt_light* lights, int32_t n_lights,
+    const rt_features* features, const rt_params* params, int32_t width, int32_t height, int32_t row_block, rt_comm* comm,
+    int32_t root, float* frame, int32_t device_ptr, void* stream, rt_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

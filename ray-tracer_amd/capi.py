@@ -363,6 +363,12 @@ class Library:
         lib.rt_bloom_static_max_pixels.argtypes = []
         lib.rt_default_params.argtypes = [C.POINTER(Params)]
         lib.rt_default_params.restype = None
+        lib.rt_comm_unique_id.argtypes = [C.c_void_p]
+        lib.rt_comm_init_rank.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        lib.rt_comm_init_all.argtypes = [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.rt_comm_destroy.argtypes = [C.c_void_p]
+        lib.rt_comm_destroy.restype = None
+        lib.rt_gather_blocks.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
 
     def check(self, status):
         if status != 0:
@@ -445,6 +451,26 @@ class Library:
         h, w = img.shape[0], img.shape[1]
         self.check(self.lib.rt_bloom(img.ctypes.data, w, h, C.byref(params), 0, None))
         return img
+
+    # ---- frame assembly across GPUs (RCCL under the C ABI)
+    def comm_unique_id(self):
+        """rt_comm_unique_id: 128 bytes that rank 0 hands to the other ranks by whatever channel there is."""
+        buf = (C.c_uint8 * 128)()
+        self.check(self.lib.rt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id, rank, world):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self.check(self.lib.rt_comm_init_rank(buf, rank, world, C.byref(h)))
+        return h
+
+    def comm_destroy(self, comm):
+        self.lib.rt_comm_destroy(comm)
+
+    def gather_blocks(self, comm, root, share_ptr, frame_ptr, width, height, row_block, stream=None):
+        """rt_gather_blocks: every rank's row blocks (device memory) into the root's device frame; queued on `stream`."""
+        self.check(self.lib.rt_gather_blocks(comm, root, share_ptr, frame_ptr, width, height, row_block, stream))
 
     def bloom_device(self, ptr, width, height, params, stream=None):
         """rt_bloom in place on a device frame (queued on `stream`, no wait)."""

@@ -82,6 +82,9 @@ hipError_t upload(DevBuf& buf, const std::vector<T>& v)
 
 } // namespace
 
+// (for the library's other translation units: sets the calling thread's error text)
+rt_status rt_set_error(rt_status code, const std::string& msg) { return fail(code, msg); }
+
 // Share of the scene's triangle area that belongs to specular materials (ks != 0): how much of what a camera ray can
 // hit spawns reflection rays.
 float specular_area_share(const HostScene& scene)
@@ -177,8 +180,9 @@ struct rt_bvh {
     size_t numRefNodes = 0, numRefPrims = 0;
     SceneView view {};
     // `lock` guards the upload and the buffers of the batch entry points (those calls run one at a time)
-    std::mutex lock;
+    std::mutex lock, gatherLock;
     DevBuf rays, hits, misc;
+    DevBuf gatherShare, gatherFrame; // rt_render_blocks_gather: this rank's blocks, and on the root the assembled frame
     // scratch sets of rt_render, guarded by `poolLock`
     enum { MAX_SCRATCH_SETS = 8 };
     std::mutex poolLock;
@@ -602,7 +606,7 @@ void rt_bvh_destroy(rt_bvh* b)
 {
     if (!b) return;
     b->pool.clear(); // (waits for whatever a call left queued on a set)
-    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->refNodes, &b->refPrims, &b->rays, &b->hits, &b->misc }) d->release();
+    for (DevBuf* d : { &b->nodes, &b->prims, &b->attrs, &b->primOrder, &b->refNodes, &b->refPrims, &b->rays, &b->hits, &b->misc, &b->gatherShare, &b->gatherFrame }) d->release();
     delete b;
 }
 
@@ -716,6 +720,52 @@ rt_status rt_render_blocks(const rt_bvh* cb, const rt_camera* camera, const rt_l
         rows += bottom - top;
     }
     return render_rows(cb, camera, lights, nLights, features, params, width, height, int32_t(rows), firstBlock * rowBlock, rowBlock, blockStride, outRgb, devicePtr, stream, stats);
+}
+
+rt_status rt_render_blocks_gather(const rt_bvh* cb, const rt_camera* camera, const rt_light* lights, int32_t nLights, const rt_features* features,
+    const rt_params* params, int32_t width, int32_t height, int32_t rowBlock, rt_comm* comm, int32_t root, float* frame, int32_t devicePtr, void* stream,
+    rt_stats* stats)
+{
+    rt_bvh* b = const_cast<rt_bvh*>(cb);
+    if (!b || !comm) return fail(RT_ERR_INVALID, "rt_render_blocks_gather: null argument");
+    const int32_t rank = rt_comm_rank(comm), world = rt_comm_world(comm);
+    if (width <= 0 || height <= 0 || rowBlock <= 0 || root < 0 || root >= world) return fail(RT_ERR_INVALID, "rt_render_blocks_gather: bad frame, block layout or root");
+    if (rank == root && !frame) return fail(RT_ERR_INVALID, "rt_render_blocks_gather: the root needs a frame");
+    const int64_t nBlocks = (int64_t(height) + rowBlock - 1) / rowBlock;
+    int64_t rows = 0;
+    for (int64_t blk = rank; blk < nBlocks; blk += world) rows += (blk * rowBlock + rowBlock < height ? rowBlock : height - blk * rowBlock);
+    // (calls on one hierarchy take turns here: they share its two buffers)
+    std::lock_guard<std::mutex> turn(b->gatherLock);
+    {
+        std::lock_guard<std::mutex> guard(b->lock);
+        rt_status up = upload_bvh(b);
+        if (up != RT_OK) return up;
+    }
+    RT_HIP(hipSetDevice(b->scene->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t frameBytes = size_t(width) * size_t(height) * 12;
+    RT_HIP(b->gatherShare.reserve(size_t(rows > 0 ? rows : 1) * size_t(width) * 12));
+    float* share = static_cast<float*>(b->gatherShare.ptr);
+    float* frameDev = nullptr;
+    if (rank == root) {
+        frameDev = frame;
+        if (!devicePtr) {
+            RT_HIP(b->gatherFrame.reserve(frameBytes));
+            frameDev = static_cast<float*>(b->gatherFrame.ptr);
+        }
+    }
+    rt_stats local;
+    if (rows > 0) {
+        const rt_status st = rt_render_blocks(cb, camera, lights, nLights, features, params, width, height, rowBlock, rank, world, share, 1, stream, stats ? stats : &local);
+        if (st != RT_OK) return st; // (the other ranks then wait in their gather: the caller has to tear the job down)
+    } else if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+    }
+    const rt_status g = rt_gather_blocks(comm, root, share, frameDev, width, height, rowBlock, stream);
+    if (g != RT_OK) return g;
+    if (rank == root && !devicePtr) RT_HIP(hipMemcpyAsync(frame, frameDev, frameBytes, hipMemcpyDeviceToHost, s));
+    RT_HIP(hipStreamSynchronize(s)); // the share buffer (and a host frame) must be done with when the call returns
+    return RT_OK;
 }
 
 namespace {

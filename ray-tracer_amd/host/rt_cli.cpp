@@ -1,11 +1,13 @@
 // Command-line renderer: the reference's "command_line_rendering" mode (reference src/main.cpp:499-556).
-//   rt_cli <config.toml> [--gpus N] [--tiles T] [--print-config]
+//   rt_cli <config.toml> [--gpus N] [--tiles T] [--gather-on-device] [--print-config]
 // Reads the configuration, prints it, loads the scene (a prebuilt one, or an OBJ file with the configured lights),
 // builds the hierarchy and renders one bitmap per configured camera into the output directory, named
 // <scene>_<start time>_cam_<index>.bmp like the reference's.  The reference gives every camera a CPU thread; here
 // the cameras are dealt round-robin to N GPUs (default 1), one host thread and one copy of the hierarchy per GPU.
 // With --tiles T (> 1) the cameras are rendered one after the other instead, each frame's rows dealt in blocks of 16 to T
 // shares spread over the N GPUs (renderRayTracingTiled: the reference's row parallelism across GPUs; T may exceed N).
+// --gather-on-device (with T = N, a share per GPU): the shares are gathered GPU to GPU by RCCL instead of through host
+// memory.
 // --print-config stops after printing (used by the tests).  The interactive window of the reference is not part
 // of this program: a configuration with command_line_rendering = false is refused.
 #include "rt_config.h"
@@ -25,16 +27,17 @@ int main(int argc, char** argv)
 {
     const char* configFile = nullptr;
     int gpus = 1, tiles = 1;
-    bool printOnly = false;
+    bool printOnly = false, gatherOnDevice = false;
     for (int i = 1; i < argc; i++) {
         if (std::strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) gpus = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--tiles") == 0 && i + 1 < argc) tiles = std::atoi(argv[++i]);
         else if (std::strcmp(argv[i], "--print-config") == 0) printOnly = true;
+        else if (std::strcmp(argv[i], "--gather-on-device") == 0) gatherOnDevice = true;
         else if (!configFile) configFile = argv[i];
         else configFile = "";
     }
     if (!configFile || !*configFile || gpus < 1 || tiles < 1) {
-        std::fprintf(stderr, "usage: rt_cli <config.toml> [--gpus N] [--tiles T] [--print-config]\n");
+        std::fprintf(stderr, "usage: rt_cli <config.toml> [--gpus N] [--tiles T] [--gather-on-device] [--print-config]\n");
         return 2;
     }
     Config config;
@@ -106,7 +109,8 @@ int main(int argc, char** argv)
             screen.writeBitmapToFile(file);
         }
     };
-    if (tiles > 1) {
+    if (tiles > 1 || gatherOnDevice) {
+        tiledGatherOnDevice = gatherOnDevice;
         // one hierarchy per GPU (built by a thread that has selected it), every camera's frame dealt to `tiles` shares
         std::vector<std::unique_ptr<BvhInterface>> bvhs;
         bvhs.resize(size_t(gpus));

@@ -25,6 +25,7 @@ bool debugBloom = false;
 int gaussian = 1;
 float scale = 1.0f;
 bool extr_enabledSkyBox = false, extr_enabledReflMap = false;
+bool tiledGatherOnDevice = false;
 int extr_max_level = 32, extr_sah_bins = 64;
 unsigned renderSeed = 1;
 
@@ -358,6 +359,28 @@ void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const st
     std::vector<std::vector<float>> parts { size_t(n) };
     std::vector<std::string> errors { size_t(n) };
     std::vector<std::thread> threads;
+    // GPU-to-GPU gather: a communicator per share, which needs every share on a device of its own
+    std::vector<rt_comm*> comms(size_t(n), nullptr);
+    struct CommGuard {
+        std::vector<rt_comm*>& comms;
+        ~CommGuard()
+        {
+            for (rt_comm* c : comms) rt_comm_destroy(c);
+        }
+    } commGuard { comms };
+    bool onDevice = tiledGatherOnDevice;
+    for (int i = 0; i < n && onDevice; i++)
+        for (int j = 0; j < i; j++)
+            if (shares[size_t(i)].device == shares[size_t(j)].device) onDevice = false;
+    if (onDevice) {
+        std::vector<int32_t> devices;
+        for (const RenderShare& sh : shares) devices.push_back(sh.device);
+        if (rt_comm_init_all(n, devices.data(), comms.data()) != RT_OK) {
+            std::fprintf(stderr, "renderRayTracingTiled: no GPU-to-GPU gather (%s); the shares come back through host memory\n", rt_last_error());
+            onDevice = false;
+        }
+    }
+    float* const screenPixels = reinterpret_cast<float*>(screen.pixels().data());
     // (whatever happens below, every thread that was started is joined before this function is left)
     struct Joiner {
         std::vector<std::thread>& threads;
@@ -370,6 +393,14 @@ void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const st
     auto share_job = [&](int i) {
             if (!shares[size_t(i)].bvh || !shares[size_t(i)].bvh->handle()) {
                 errors[size_t(i)] = "share " + std::to_string(i) + " has no hierarchy";
+                return;
+            }
+            if (onDevice) {
+                // every rank of the communicator takes part, also one without rows; rank 0 receives the frame
+                if (rt_init(shares[size_t(i)].device) != RT_OK ||
+                    rt_render_blocks_gather(shares[size_t(i)].bvh->handle(), &cam, lights.data(), int32_t(lights.size()), &f, &p, res.x, res.y, rowBlock,
+                        comms[size_t(i)], 0, i == 0 ? screenPixels : nullptr, 0, nullptr, nullptr) != RT_OK)
+                    errors[size_t(i)] = rt_last_error();
                 return;
             }
             int rows = 0;
@@ -394,8 +425,8 @@ void renderRayTracingTiled(const Scene& scene, const Trackball& camera, const st
             std::fprintf(stderr, "renderRayTracingTiled: %s\n", e.c_str());
             return;
         }
-    float* out = reinterpret_cast<float*>(screen.pixels().data());
-    for (int i = 0; i < n; i++) {
+    float* out = screenPixels;
+    for (int i = 0; i < n && !onDevice; i++) {
         size_t at = 0;
         for (int b = i; b < nBlocks; b += n) {
             const int top = b * rowBlock, bottom = std::min(res.y, top + rowBlock);

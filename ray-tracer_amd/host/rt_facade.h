@@ -134,6 +134,7 @@ extern float scale;
 extern bool extr_enabledSkyBox, extr_enabledReflMap;
 extern int extr_max_level, extr_sah_bins;
 extern unsigned renderSeed; // no counterpart: seed of the counter-based random stream
+extern bool tiledGatherOnDevice; // no counterpart: renderRayTracingTiled gathers the shares GPU to GPU (RCCL), see there
 
 class BvhInterface {
 public:
@@ -206,6 +207,11 @@ void renderRayTracing(const Scene& scene, const Trackball& camera, const BvhInte
 // shares[i].bvh after rt_init(shares[i].device), the shares are put together in `screen` and bloom runs on the
 // assembled frame.  Every hierarchy must have been built from `scene`; several shares may use the same hierarchy
 // (they then take turns on it).  Random streams are keyed by pixel, so the frame does not depend on the shares.
+// By default every share comes back through host memory.  With `tiledGatherOnDevice` set and every share on a device of
+// its own, the shares are gathered GPU to GPU instead (rt_render_blocks_gather: grouped RCCL sends / receives into the
+// first share's device, one device-to-host copy of the assembled frame); with a single share the same path runs on a
+// one-rank communicator.  A hierarchy must have been built on its share's device (BvhInterface builds on the GPU that
+// is current at construction).
 struct RenderShare {
     const BvhInterface* bvh;
     int device;

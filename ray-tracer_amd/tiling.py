@@ -90,3 +90,22 @@ def assemble(gathered, world, width, height, block=ROW_BLOCK):
             top, bottom, _, _ = block_rows(b, height, block)
             frame[top:bottom] = gathered[r][k * block:k * block + (bottom - top)]
     return frame
+
+
+def native_comm(lib, rank, world):
+    """A communicator of the library's own (rt_comm_init_rank) for gather_frame_native: rank 0 draws the id and the
+    other ranks get it through torch.distributed (whatever backend the process group runs on)."""
+    ident = [lib.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ident, src=0)
+    return lib.comm_init_rank(ident[0], rank, world)
+
+
+def gather_frame_native(lib, comm, local, rank, world, width, height, block=ROW_BLOCK, frame=None, stream=None):
+    """gather_frame through the C ABI: rt_gather_blocks sends every block straight into its place in rank 0's frame
+    (grouped RCCL sends / receives issued by the library itself: no stacked tile stores, no row gather afterwards).
+    Returns the [height, width, 3] frame on rank 0, None elsewhere."""
+    if rank == 0 and frame is None:
+        frame = torch.empty((height, width, 3), dtype=local.dtype, device=local.device)
+    lib.gather_blocks(comm, 0, local.data_ptr(), frame.data_ptr() if rank == 0 else None, width, height, block, stream)
+    return frame if rank == 0 else None

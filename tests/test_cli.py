@@ -106,10 +106,11 @@ def read_bmp(path, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--tiles", "3"]], ids=["whole-frames", "row-tiles"])
+@pytest.mark.parametrize("extra", [[], ["--tiles", "3"], ["--gather-on-device"]], ids=["whole-frames", "row-tiles", "device-gather"])
 def test_prebuilt_scene_through_the_program_matches_the_golden_image(tmp_path, extra):
     """Scene 8 (spheres: no data files), the golden frame size and camera, shading + hard shadows; once a camera per
-    call, once every frame dealt in 16-row blocks to three shares (the multi-GPU row tiling, here on one GPU)."""
+    call, once every frame dealt in 16-row blocks to three shares (the multi-GPU row tiling, here on one GPU), once
+    through the GPU-to-GPU gather (rt_render_blocks_gather on a one-rank RCCL communicator: one GPU is all there is)."""
     W, H = o.SIZE_A
     out = tmp_path / "out"
     cfg = tmp_path / "spheres.toml"
