@@ -887,6 +887,12 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             return v < 1 ? 1 : v;
         }();
         P.primaryBudget = primaryBudget;
+        static const int primaryStack = [] {
+            const char* e = std::getenv("RT_PRIMARY_STACK"); // tuning / test knob; default chosen by measurement
+            const int v = e ? std::atoi(e) : 10;
+            return v < 1 ? 1 : v;
+        }();
+        P.primaryStack = primaryStack < b->host.numLevels ? primaryStack : (b->host.numLevels > 0 ? b->host.numLevels : 1);
         static const int smallPass = [] {
             const char* e = std::getenv("RT_PRIMARY_SMALL_PASS"); // tuning knob; default chosen by measurement
             return e ? std::atoi(e) : 40;

@@ -104,6 +104,7 @@ struct FrameParams {
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
                                        // primary pass: the camera rays (sample * pixels + pixel) that gave up
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
+    int32_t primaryStack;              // ... and the stack entries it may hold
     int32_t primarySmallPass;          // a pass with fewer tiles per resident wave than this runs with a budget of 32
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
@@ -354,11 +355,13 @@ struct Stack {
 // Returns the slot of the accepted primitive (or -1) and updates tmax.  An any-hit query returns at the
 // first accepted triangle: the reference's boolean is the same because acceptance is what sets it.
 //
-// BUDGET: a query that has visited `budget` inner nodes without accepting anything gives up and returns
-// TRAVERSE_GAVE_UP; the caller hands it to a kernel that shares such a ray's boxes among all lanes.
+// BUDGET: a query that has visited `budget` inner nodes without accepting anything, or that needs more than `stackLimit`
+// stack entries, gives up and returns TRAVERSE_GAVE_UP; the caller hands it to kernels that finish such rays (the
+// first kind skims along the surface through thousands of boxes; the second kind is rare, and a short stack is what
+// lets the kernel keep twice the waves resident).
 constexpr int TRAVERSE_GAVE_UP = -2;
 template <bool PRUNE, bool ANY, bool COUNT, bool SPH, bool BUDGET = false>
-__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt, Attr& attr, int budget = 0)
+__device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st, Counts& cnt, Attr& attr, int budget = 0, int stackLimit = 0)
 {
     attr.slot = -1;
     attr.t = tmax;
@@ -395,6 +398,11 @@ __device__ int traverse(const SceneView& S, const RayD& r, float& tmax, Stack st
                 const int32_t refL = node_ref_left(nd), refR = node_ref_right(nd);
                 if (vL && vR) {
                     const bool leftFirst = tL < tR;
+#ifdef RT_SP_HIST
+                    if (BUDGET && sp + 1 > int(cnt.overflow)) cnt.overflow = uint32_t(sp + 1);
+#endif
+                    // (a budgeted query runs on a short stack: 99.98 % of camera rays never hold more than ten entries)
+                    if (BUDGET && sp >= stackLimit) return TRAVERSE_GAVE_UP;
                     st.push(sp++, leftFirst ? refR : refL, leftFirst ? tR : tL);
                     cur = leftFirst ? refL : refR;
                     curT = leftFirst ? tL : tR;

@@ -191,7 +191,18 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
             const RayD r = make_ray(o, d);
             cnt.primary++;
             Attr attr;
-            slot = traverse<PRUNE, false, COUNT, false, true>(P.scene, r, t, st, cnt, attr, P.primaryBudget);
+#ifdef RT_SP_HIST
+            cnt.overflow = 0;
+#endif
+            slot = traverse<PRUNE, false, COUNT, false, true>(P.scene, r, t, st, cnt, attr, P.primaryBudget, P.primaryStack);
+#ifdef RT_SP_HIST
+            if (P.stats) {
+                const uint32_t m = cnt.overflow;
+                atomicAdd(&P.stats[STAT_DEBUG0 + (m <= 4 ? 0 : m <= 6 ? 1 : m <= 8 ? 2 : m <= 10 ? 3 : m <= 12 ? 4 : 5)], 1ull);
+                atomicAdd(&P.stats[STAT_DEBUG0 + 6], (unsigned long long)m);
+            }
+            cnt.overflow = 0;
+#endif
             // (a centre ray that gave up gets its flag from the kernel that finishes it)
             if (dof && id.sidx == 0 && slot != TRAVERSE_GAVE_UP) P.dofFlags[id.pix] = dof_flag(P, d, slot >= 0 ? t : FLT_MAX) ? 1 : 0;
             if (slot == -1) {
@@ -1592,18 +1603,20 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
     const size_t streamLds = stream_lds_bytes(P.pairStackLds);
     {
         // enough chunks for every resident wave to come back to the cursor several times
-        const uint32_t waves = P.countTests ? resident_blocks(k_primary<PRUNE, true>, WAVE, lds) : resident_blocks(k_primary<PRUNE, false>, WAVE, lds);
+        const uint32_t waves = P.countTests ? resident_blocks(k_primary<PRUNE, true>, WAVE, size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2))
+                                            : resident_blocks(k_primary<PRUNE, false>, WAVE, size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2));
         uint32_t chunk = P.logicalBlocks / (waves * 8u);
         chunk = chunk < 1u ? 1u : (chunk > PRIMARY_CHUNK_MAX ? PRIMARY_CHUNK_MAX : chunk);
         FrameParams Q = P;
         Q.primaryChunk = chunk;
+        const size_t ldsPrimary = size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2);
         // A small pass (a rank's share of a frame on several GPUs) ends when its slowest tile does, and the slowest
         // tiles are the ones whose rays use up the whole budget: with few tiles per wave a smaller budget shortens
         // the pass (measured: 1/8 of the headline frame 1.18 -> 1.00 ms), with many it only moves work to the
         // kernels behind (whole frame 2.69 -> 3.59 ms).
         if (P.logicalBlocks < waves * uint32_t(P.primarySmallPass) && Q.primaryBudget > 32) Q.primaryBudget = 32;
-        if (Q.countTests) launch_walkers(k_primary<PRUNE, true>, Q, lds, stream);
-        else launch_walkers(k_primary<PRUNE, false>, Q, lds, stream);
+        if (Q.countTests) launch_walkers(k_primary<PRUNE, true>, Q, ldsPrimary, stream);
+        else launch_walkers(k_primary<PRUNE, false>, Q, ldsPrimary, stream);
     }
     auto finish_gave_up = [&](hipStream_t st) {
         // how many rays gave up, and how many of those meet a primitive, is only known on the device: both kernels

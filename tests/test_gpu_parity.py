@@ -363,11 +363,14 @@ def test_bumpy_mesh_depth_of_field_soft_shadows_match_oracle(lib):
 
 
 @pytest.mark.skipif(os.environ.get("RT_TEST_CHILD") == "1", reason="already the child run")
-def test_small_limits_take_the_spill_and_give_up_paths():
+@pytest.mark.parametrize("knobs", [dict(RT_PAIR_STACK_LDS="64", RT_PRIMARY_BUDGET="2"), dict(RT_PRIMARY_STACK="1"), dict(RT_PRIMARY_STACK="3")],
+                         ids=["budget-2", "stack-1", "stack-3"])
+def test_small_limits_take_the_spill_and_give_up_paths(knobs):
     """Same image tests in a child process with the pair stack's LDS share at its minimum (every deeper stack spills
     to device memory) and a camera-ray budget of two nodes (nearly every ray that enters the root box goes through
-    the give-up queue, the stream kernel and the unbudgeted traversal)."""
-    env = dict(os.environ, RT_TEST_CHILD="1", RT_PAIR_STACK_LDS="64", RT_PRIMARY_BUDGET="2")
+    the give-up queue, the stream kernel and the unbudgeted traversal); and with a camera-ray stack of one or three
+    entries (rays give up in the middle of their traversal, many of them with a hit already accepted)."""
+    env = dict(os.environ, RT_TEST_CHILD="1", **knobs)
     cmd = [sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__),
            "-k", "bumpy or row_tiles or (images_match and (soft or shading or hard or sky))"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
