@@ -298,7 +298,13 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
     const uint32_t perHit = uint32_t(P.shadowSamplesPerHit);
     const int lane = int(threadIdx.x) & 63;
-    const unsigned int rounded = qBegin + ((nHits - qBegin + 63u) & ~63u); // whole waves stay in the loop together
+    const unsigned int rounded = qBegin + ((nHits - qBegin + BLOCK - 1u) & ~(BLOCK - 1u)); // whole blocks stay in the loop together
+    // The waves of a block reserve their room in the work queue with ONE atomic per block and iteration: atomics on one
+    // address are served one after the other (a few nanoseconds each), and one per wave (390,000 for the headline
+    // frame) was most of this kernel's time.
+    __shared__ uint32_t waveTotals[2][BLOCK / 64];
+    __shared__ unsigned long long blockBase[2];
+    uint32_t iteration = 0;
     uint32_t culled = 0;
     bool everyLightShadowed = true;
     for (int li = 0; li < P.nLights; li++)
@@ -323,6 +329,41 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
         }
         const vec3 point = r.o + (r.d * t);
         const vec3 N = normalize(s.normal);
+        // Most hits face a light with all of its samples or with none: decided from the light's corners.  Every sample
+        // position lies within their hull (the sample parameters stay in [0, 1)), and N . (position - point) is linear
+        // in the position, so its extremes over the samples are attained at corners.  Where the smallest corner value
+        // exceeds a margin far above the rounding of the per-sample expression (relative 1e-4 against about 1e-6),
+        // every sample's own test below would come out positive, where the largest is below minus the margin, none
+        // would: those hits skip the per-sample evaluation (random draws, square root, divide).  Two bits per light: 1 =
+        // all samples wanted, 2 = none, 0 = decide sample by sample.
+        uint32_t lightClass = 0;
+        if (live && P.f.shading)
+            for (int li = 0; li < P.nLights; li++) {
+                const LightDev& L = P.lights[li];
+                if (L.shadowBase < 0 || L.type == RT_LIGHT_POINT) continue;
+                vec3 corner[4];
+                int corners = 2;
+                corner[0] = load3(L.v);
+                if (L.type == RT_LIGHT_SEGMENT) {
+                    corner[1] = load3(L.v + 3);
+                } else {
+                    corner[1] = corner[0] + load3(L.v + 3);
+                    corner[2] = corner[0] + load3(L.v + 6);
+                    corner[3] = corner[1] + load3(L.v + 6);
+                    corners = 4;
+                }
+                float lowest = FLT_MAX, highest = -FLT_MAX, farthest = 0.0f;
+                for (int c = 0; c < corners; c++) {
+                    const vec3 toCorner = corner[c] - point;
+                    const float d = dot(N, toCorner);
+                    lowest = d < lowest ? d : lowest;    // (a NaN leaves both as they are: decided sample by sample)
+                    highest = d > highest ? d : highest;
+                    farthest = fmaxf(farthest, dot(toCorner, toCorner));
+                }
+                const float margin = 0.0001f * sqrtf(farthest);
+                if (lowest > margin && lowest <= FLT_MAX) lightClass |= 1u << (2 * li);
+                else if (highest < -margin && highest >= -FLT_MAX) lightClass |= 2u << (2 * li);
+            }
         // pass 0 decides and counts this hit's shadow rays (the first 64 decisions are kept as a bit mask), pass 1
         // writes them at the offset the wave reserved
         uint32_t need = 0;
@@ -336,10 +377,19 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                     if (lane >= off) prefix += v;
                 }
                 const uint32_t total = __shfl(prefix, 63, 64);
-                unsigned long long base = 0;
-                if (lane == 63 && total) base = atomicAdd(&P.queueCounters[Q_SHADOW_ITEMS], (unsigned long long)total);
-                base = __shfl(base, 63, 64);
-                at = uint32_t(base) + prefix - need;
+                const uint32_t wave = threadIdx.x >> 6, slot = iteration & 1u;
+                if (lane == 63) waveTotals[slot][wave] = total;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    uint32_t sum = 0;
+                    for (uint32_t w = 0; w < BLOCK / 64; w++) sum += waveTotals[slot][w];
+                    blockBase[slot] = sum ? atomicAdd(&P.queueCounters[Q_SHADOW_ITEMS], (unsigned long long)sum) : 0ull;
+                }
+                __syncthreads();
+                uint32_t before = 0;
+                for (uint32_t w = 0; w < wave; w++) before += waveTotals[slot][w];
+                at = uint32_t(blockBase[slot]) + before + prefix - need;
+                iteration++;
             }
             if (live) {
                 for (int li = 0; li < P.nLights; li++) {
@@ -350,8 +400,11 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                     for (int k = 0; k < total; k++) {
                         const int j = L.shadowBase + k;
                         bool wanted = true;
+                        const uint32_t decided = (lightClass >> (2 * li)) & 3u;
                         if (pass == 1 && j < 64) {
                             wanted = (wantedBits >> j) & 1ull;
+                        } else if (decided != 0u) {
+                            wanted = decided == 1u;
                         } else if (P.f.shading) {
                             vec3 position, color;
                             light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter + uint32_t(L.drawBase) + uint32_t(k) * per, position, color);
