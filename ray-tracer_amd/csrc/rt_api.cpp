@@ -122,7 +122,7 @@ struct rt_scene {
 // pool and gives it back when it returns, so calls on one rt_bvh from several threads (the reference renders one camera
 // per thread from one BvhInterface, src/main.cpp:533-552) run side by side, each on its own set.
 struct RenderScratch {
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, shadeList, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
     // second stream (and its fork / join events) on which a direct-lighting pass finishes its long camera rays, and the
     // two marks around that stream's shadow kernel
@@ -162,7 +162,7 @@ struct RenderScratch {
             (void)hipStreamDestroy(ownStream);
         }
         if (wfReport) (void)hipHostFree(wfReport);
-        for (DevBuf* d : { &stats, &frame, &queue, &queueCounters, &visibility, &shadowQueue, &pairSpill, &samples, &dofFlags, &wfRays, &wfNodes, &wfMeta, &wfValue, &wfHits, &wfHitNode, &wfGlossy, &gaveUpQueue, &pairSpillAux })
+        for (DevBuf* d : { &stats, &frame, &queue, &queueCounters, &visibility, &shadowQueue, &shadeList, &pairSpill, &samples, &dofFlags, &wfRays, &wfNodes, &wfMeta, &wfValue, &wfHits, &wfHitNode, &wfGlossy, &gaveUpQueue, &pairSpillAux })
             d->release();
         for (hipEvent_t ev : { evStart, evMid, evStop, evSplit[0], evSplit[1], evSplit[2], evSplit[3], evShadowB[0], evShadowB[1], evFork, evJoin, done })
             if (ev) (void)hipEventDestroy(ev);
@@ -1010,6 +1010,10 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
         RT_HIP(w->visibility.reserve(items));
         RT_HIP(w->shadowQueue.reserve(items * sizeof(uint32_t)));
         P.shadowQueue = static_cast<uint32_t*>(w->shadowQueue.ptr);
+        if (P.shadowSamplesPerHit > 0) {
+            RT_HIP(w->shadeList.reserve(cap * sizeof(uint32_t)));
+            P.shadeList = static_cast<uint32_t*>(w->shadeList.ptr);
+        }
         rt::size_pair_stack(P);
         if (P.pairSpillEntries > 0) {
             RT_HIP(w->pairSpill.reserve(size_t(P.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));

@@ -103,6 +103,9 @@ struct FrameParams {
     uint32_t shadowQueueItems;         // lighting round shares the buffer with the first); its capacity in items
     uint32_t* shadowQueue;             // work items hit * shadowSamplesPerHit + j that need a shadow ray; during the
                                        // primary pass: the camera rays (sample * pixels + pixel) that gave up
+    uint32_t* shadeList;               // hit-queue entries whose colour the shade pass computes (written by the cull pass:
+                                       // the others are black and done); as many entries as the queue, filled from the
+                                       // front, or from the back when shadowQueueReversed is set
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
     int32_t primaryStack;              // ... and the stack entries it may hold
     int32_t primarySmallPass;          // a pass with fewer tiles per resident wave than this runs with a budget of 32
@@ -151,7 +154,8 @@ enum {
     Q_RANGE_END = Q_RANGE_BEGIN + 16,   // set by k_range once the entries exist
     Q_SHADOW_XCD = Q_RANGE_END + 16,    // 8 cursors (one per 128-byte line): shadow packets handed out per eighth of the queue
     Q_WF_GEN = Q_SHADOW_XCD + 8 * 16,   // wavefront: generation table, entry g = nodes allocated when generation g's trace began
-    Q_COUNT = Q_WF_GEN + 64
+    Q_SHADE_ITEMS = Q_WF_GEN + 64,      // hits of the round that the shade pass has to evaluate (the cull pass lists them)
+    Q_COUNT = Q_SHADE_ITEMS + 16
 };
 enum { WF_MAX_GENERATIONS = 60 };        // (the table's size; ray_depth <= 8 and at most 24 see-through continuations)
 

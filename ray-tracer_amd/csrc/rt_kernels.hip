@@ -302,8 +302,8 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     // The waves of a block reserve their room in the work queue with ONE atomic per block and iteration: atomics on one
     // address are served one after the other (a few nanoseconds each), and one per wave (390,000 for the headline
     // frame) was most of this kernel's time.
-    __shared__ uint32_t waveTotals[2][BLOCK / 64];
-    __shared__ unsigned long long blockBase[2];
+    __shared__ uint32_t waveTotals[2][BLOCK / 64], waveShade[2][BLOCK / 64];
+    __shared__ unsigned long long blockBase[2], blockShadeBase[2];
     uint32_t iteration = 0;
     uint32_t culled = 0;
     bool everyLightShadowed = true;
@@ -378,17 +378,34 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
                 }
                 const uint32_t total = __shfl(prefix, 63, 64);
                 const uint32_t wave = threadIdx.x >> 6, slot = iteration & 1u;
-                if (lane == 63) waveTotals[slot][wave] = total;
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    uint32_t sum = 0;
-                    for (uint32_t w = 0; w < BLOCK / 64; w++) sum += waveTotals[slot][w];
-                    blockBase[slot] = sum ? atomicAdd(&P.queueCounters[Q_SHADOW_ITEMS], (unsigned long long)sum) : 0ull;
+                // (the same step lists the hits the shade pass has to evaluate: all but those written off below)
+                const bool toShade = live && !(need == 0 && P.f.shading && everyLightShadowed);
+                const unsigned long long shadeVotes = __ballot(toShade);
+                if (lane == 63) {
+                    waveTotals[slot][wave] = total;
+                    waveShade[slot][wave] = uint32_t(__popcll(shadeVotes));
                 }
                 __syncthreads();
-                uint32_t before = 0;
-                for (uint32_t w = 0; w < wave; w++) before += waveTotals[slot][w];
+                if (threadIdx.x == 0) {
+                    uint32_t sum = 0, shade = 0;
+                    for (uint32_t w = 0; w < BLOCK / 64; w++) {
+                        sum += waveTotals[slot][w];
+                        shade += waveShade[slot][w];
+                    }
+                    blockBase[slot] = sum ? atomicAdd(&P.queueCounters[Q_SHADOW_ITEMS], (unsigned long long)sum) : 0ull;
+                    blockShadeBase[slot] = shade ? atomicAdd(&P.queueCounters[Q_SHADE_ITEMS], (unsigned long long)shade) : 0ull;
+                }
+                __syncthreads();
+                uint32_t before = 0, shadeBefore = 0;
+                for (uint32_t w = 0; w < wave; w++) {
+                    before += waveTotals[slot][w];
+                    shadeBefore += waveShade[slot][w];
+                }
                 at = uint32_t(blockBase[slot]) + before + prefix - need;
+                if (toShade && P.shadeList) {
+                    const uint32_t pos = uint32_t(blockShadeBase[slot]) + shadeBefore + lanes_below(shadeVotes);
+                    P.shadeList[P.shadowQueueReversed ? uint32_t(P.queueCapacity) - 1u - pos : pos] = q;
+                }
                 iteration++;
             }
             if (live) {
@@ -986,7 +1003,12 @@ __global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
 {
     const unsigned int qBegin = (unsigned int)P.queueCounters[Q_RANGE_BEGIN], nHits = (unsigned int)P.queueCounters[Q_RANGE_END];
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
-    for (unsigned int q = qBegin + blockIdx.x * BLOCK + threadIdx.x; q < nHits; q += gridDim.x * BLOCK) {
+    // with a cull pass before it, the kernel walks the list of hits that pass left to shade (full waves); otherwise the
+    // round's part of the hit queue
+    const bool listed = P.shadeList != nullptr && P.shadowSamplesPerHit > 0;
+    const unsigned int first = listed ? 0u : qBegin, count = listed ? (unsigned int)P.queueCounters[Q_SHADE_ITEMS] : nHits;
+    for (unsigned int i = first + blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const unsigned int q = listed ? P.shadeList[P.shadowQueueReversed ? uint32_t(P.queueCapacity) - 1u - i : i] : i;
         const HitEntry e = P.queue[q];
         if (e.slot < 0 || e.pad != 0) continue; // nothing found after all / colour already written by k_cull
         Rng rng;
