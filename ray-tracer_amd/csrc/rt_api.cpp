@@ -122,7 +122,7 @@ struct rt_scene {
 // pool and gives it back when it returns, so calls on one rt_bvh from several threads (the reference renders one camera
 // per thread from one BvhInterface, src/main.cpp:533-552) run side by side, each on its own set.
 struct RenderScratch {
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, shadeList, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, shadeList, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux, laneStacks;
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
     // second stream (and its fork / join events) on which a direct-lighting pass finishes its long camera rays, and the
     // two marks around that stream's shadow kernel
@@ -162,7 +162,7 @@ struct RenderScratch {
             (void)hipStreamDestroy(ownStream);
         }
         if (wfReport) (void)hipHostFree(wfReport);
-        for (DevBuf* d : { &stats, &frame, &queue, &queueCounters, &visibility, &shadowQueue, &shadeList, &pairSpill, &samples, &dofFlags, &wfRays, &wfNodes, &wfMeta, &wfValue, &wfHits, &wfHitNode, &wfGlossy, &gaveUpQueue, &pairSpillAux })
+        for (DevBuf* d : { &stats, &frame, &queue, &queueCounters, &visibility, &shadowQueue, &shadeList, &pairSpill, &samples, &dofFlags, &wfRays, &wfNodes, &wfMeta, &wfValue, &wfHits, &wfHitNode, &wfGlossy, &gaveUpQueue, &pairSpillAux, &laneStacks })
             d->release();
         for (hipEvent_t ev : { evStart, evMid, evStop, evSplit[0], evSplit[1], evSplit[2], evSplit[3], evShadowB[0], evShadowB[1], evFork, evJoin, done })
             if (ev) (void)hipEventDestroy(ev);
@@ -1039,6 +1039,17 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             if (P.pairSpillEntries > 0) {
                 RT_HIP(w->pairSpillAux.reserve(size_t(aux.pairSpillWaves) * P.pairSpillEntries * sizeof(uint32_t)));
                 aux.pairSpill = static_cast<uint32_t*>(w->pairSpillAux.ptr);
+            }
+            // traversal stacks in device memory for that stream's per-lane kernels (no LDS: they run beside the shadow pass)
+            static const int deviceStacks = [] {
+                const char* e = std::getenv("RT_AUX_DEVICE_STACKS"); // 0: those kernels keep their stacks in LDS
+                return e ? std::atoi(e) : 1;
+            }();
+            if (deviceStacks) {
+                aux.laneStackWaves = 2048;
+                const size_t depth = size_t(b->host.numLevels > 0 ? b->host.numLevels : 1);
+                RT_HIP(w->laneStacks.reserve(size_t(aux.laneStackWaves) * depth * 64 * sizeof(uint2)));
+                aux.laneStacks = static_cast<uint2*>(w->laneStacks.ptr);
             }
             useAux = true;
         }

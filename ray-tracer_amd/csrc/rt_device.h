@@ -106,6 +106,9 @@ struct FrameParams {
     uint32_t* shadeList;               // hit-queue entries whose colour the shade pass computes (written by the cull pass:
                                        // the others are black and done); as many entries as the queue, filled from the
                                        // front, or from the back when shadowQueueReversed is set
+    uint2* laneStacks;                 // when not null: traversal stacks in device memory, [wave][entry][lane], for
+    uint32_t laneStackWaves;           // k_closest on the second stream, which then needs no LDS and fits beside the
+                                       // shadow pass that fills every CU's LDS; the waves it has room for
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
     int32_t primaryStack;              // ... and the stack entries it may hold
     int32_t primarySmallPass;          // a pass with fewer tiles per resident wave than this runs with a budget of 32

@@ -27,6 +27,8 @@ struct SplitAux {
     unsigned long long* counters;
     uint32_t* pairSpill;
     uint32_t pairSpillWaves;
+    uint2* laneStacks;       // traversal stacks in device memory for that stream's per-lane kernels (FrameParams::laneStacks)
+    uint32_t laneStackWaves;
 };
 hipError_t launch_render(const FrameParams& P, hipStream_t stream, hipEvent_t afterPasses, hipEvent_t* split, bool* splitRecorded,
     unsigned long long* wavefrontNodes = nullptr, const SplitAux* aux = nullptr, bool* shadowMarksRecorded = nullptr);

@@ -2,6 +2,7 @@
 // ray/triangle decisions must round exactly like the reference's scalar fp32 code.
 #include "rt_kernels.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace rt {
@@ -241,13 +242,24 @@ __global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
     flush_counts(cnt, P.stats);
 }
 
+// Where a lane of a one-wave block keeps its traversal stack: in LDS, or — for k_closest on the second stream, which has
+// to fit on CUs whose LDS the shadow pass of the first stream has taken — in the block's slice of P.laneStacks.  (With
+// its stacks in LDS the kernel waited for the shadow pass to end: 8 ms instead of 0.5, and the second lighting round
+// behind it ran after everything else.)
+__device__ __forceinline__ uint2* lane_stack(const FrameParams& P, uint2* lds)
+{
+    if (!P.laneStacks) return lds + threadIdx.x;
+    const size_t depth = size_t(P.scene.stackDepth < 1 ? 1 : P.scene.stackDepth);
+    return P.laneStacks + size_t(blockIdx.x) * depth * WAVE + threadIdx.x;
+}
+
 // Primary pass, third kernel: one lane per hit-queue entry the stream kernel appended without a primitive
 // (slot < 0); the entry's distance and primitive slot are filled in place.
 template <bool PRUNE, bool COUNT>
 __global__ void __launch_bounds__(WAVE) k_closest(const FrameParams P)
 {
     extern __shared__ uint2 lds_stack[];
-    Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
+    Stack st { lane_stack(P, lds_stack), uint32_t(WAVE) };
     Counts cnt;
     const unsigned int nHits = (unsigned int)P.primaryCounters[Q_HITS];
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
@@ -1703,10 +1715,19 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
             G.pairSpillWaves = aux->pairSpillWaves;
         }
         launch_stream<true>(G, gridDirect.x, streamLds, st);
-        const uint32_t walkers = P.countTests ? resident_blocks(k_closest<PRUNE, true>, WAVE, lds) : resident_blocks(k_closest<PRUNE, false>, WAVE, lds);
+        // (on the second stream: stacks in device memory, no LDS, so that the kernel fits beside the first round's
+        // shadow pass instead of waiting for its waves to end)
+        const bool deviceStacks = aux && aux->laneStacks;
+        if (deviceStacks) {
+            G.laneStacks = aux->laneStacks;
+            G.laneStackWaves = aux->laneStackWaves;
+        }
+        const size_t ldsClosest = deviceStacks ? 0 : lds;
+        uint32_t walkers = P.countTests ? resident_blocks(k_closest<PRUNE, true>, WAVE, ldsClosest) : resident_blocks(k_closest<PRUNE, false>, WAVE, ldsClosest);
+        if (deviceStacks && walkers > aux->laneStackWaves) walkers = aux->laneStackWaves;
         const dim3 gc(gridDirect.x < walkers ? gridDirect.x : walkers);
-        if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), lds, st, P);
-        else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), lds, st, P);
+        if (P.countTests) hipLaunchKernelGGL((k_closest<PRUNE, true>), gc, dim3(WAVE), ldsClosest, st, G);
+        else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), ldsClosest, st, G);
     };
     auto lighting = [&](const FrameParams& R, hipStream_t st, hipEvent_t* marks, hipEvent_t* shadowOnly = nullptr) {
         if (R.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, st, R);
