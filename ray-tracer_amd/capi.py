@@ -369,6 +369,8 @@ class Library:
         lib.rt_comm_destroy.argtypes = [C.c_void_p]
         lib.rt_comm_destroy.restype = None
         lib.rt_gather_blocks.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        lib.rt_render_blocks_gather.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Light), C.c_int32, C.POINTER(Features), C.POINTER(Params),
+                                                C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Stats)]
 
     def check(self, status):
         if status != 0:

@@ -151,3 +151,20 @@ def test_argument_errors(lib):
     opt = __import__("importlib").import_module("ray-tracer_amd.capi").BvhOptions(0, 40, 64)
     assert lib.lib.rt_bvh_build(sh, C.byref(opt), C.byref(h)) == 4
     lib.lib.rt_scene_destroy(sh)
+
+
+def test_gpu_only_entry_points_fail_cleanly_without_a_gpu(lib):
+    """rt_bvh_build_device and the frame-assembly calls need a GPU (and RCCL): without one they return a status and a
+    message, they do not crash; bad arguments are refused before anything is touched."""
+    import torch
+
+    assert lib.lib.rt_gather_blocks(None, 0, None, None, 4, 4, 16, None) == 1  # RT_ERR_INVALID
+    assert b"bad argument" in lib.lib.rt_last_error()
+    assert lib.lib.rt_comm_init_rank(None, 0, 1, None) == 1
+    assert lib.lib.rt_render_blocks_gather(None, None, None, 0, None, None, 4, 4, 16, None, 0, None, 0, None, None) == 1
+    lib.lib.rt_comm_destroy(None)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the GPU tests cover the working paths")
+    sc = rt.SceneData.from_golden(o.golden("cornell"))
+    with pytest.raises(rt.RtError):
+        lib.bvh_build_device(lib.scene_create(sc))
