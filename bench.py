@@ -36,7 +36,7 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X fp32 vector peak (packed fused multiply-add 
 FP32_NO_FMA_TFLOPS = 78.6  # the same without fused multiply-add: this path is compiled -ffp-contract=off by contract
 # The compiled reference as it is against the oracle, one thread each, on THIS benchmark's mesh (81,920 triangles, same
 # light, shading + soft shadows, 16 spp, 48x27 pixels = 75,200 rays): 101.3 s against 0.340 s, measured in the build
-# container (8-vCPU Xeon VM, g++ 11.4) by tools/time_reference_headline.py; BASELINE.md section 4 has the table.
+# container (8-vCPU Xeon VM, g++ 11.4) by tools/time_reference_headline.py.
 REFERENCE_AS_IS_RATIO = 298.0
 L2_PEAK_GBS = 34500.0      # MI355X aggregate L2 bandwidth (8 XCDs)
 CPU_ROW_STEP = 12          # the CPU leg renders every 12th row of the frame
