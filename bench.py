@@ -463,6 +463,22 @@ def extra_large_mesh(rt, synth, lib, cam, feats, params, out, stream):
             "counters_from": "profiles/r3_l8/summary.txt (profiles/traffic_l8.json)"}
     except (OSError, ValueError, KeyError):
         pass
+    lib.lib.rt_bvh_destroy(bvh)
+    # the surface-area-heuristic variant of the hierarchy (four sorts per node, 64 bins): build times and the same frame
+    t0 = time.perf_counter()
+    host_bvh = lib.bvh_build(sh, sah=True)
+    sah_host_s = time.perf_counter() - t0
+    lib.lib.rt_bvh_destroy(host_bvh)
+    t0 = time.perf_counter()
+    bvh, on_device = lib.bvh_build_device(sh, sah=True)
+    sah_device_s = time.perf_counter() - t0
+    best = None
+    for _ in range(4):
+        _, st = lib.render(bvh, cam, lights, n_lights, feats, params, WIDTH, HEIGHT, 0, HEIGHT, out=out.data_ptr(), device_ptr=1, stream=stream)
+        best = st.kernel_ms + st.resolve_ms if best is None else min(best, st.kernel_ms + st.resolve_ms)
+    out_d["sah_64_bins"] = {"bvh_levels": int(lib.lib.rt_bvh_num_levels(bvh)), "host_build_s": sah_host_s, "device_build_s": sah_device_s,
+                            "built_on_device": bool(on_device), "frame_ms": best}
+    lib.lib.rt_bvh_destroy(bvh)
     return out_d
 
 

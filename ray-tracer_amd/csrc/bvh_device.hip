@@ -28,6 +28,9 @@
 // ranks are closed-form from per-level tables of subtree sizes, and every node can be written by a thread of its own.
 // Boxes are combined bottom-up, a level per launch, left before right and keeping the earlier value on ties — which is
 // what the host builder's sequential fmin / fmax over the node's primitives yields (signed zeros included).
+//
+// The surface-area-heuristic variant (src/bounding_volume_hierarchy.cpp:133-190) runs on the same sorts; its part of
+// this file says how the cuts are found and the nodes numbered when the tree's shape depends on the data.
 #include "bvh_build.h"
 
 #include <hip/hip_runtime.h>
@@ -502,6 +505,265 @@ __global__ void k_prim_records(const Geometry g, int n, const Keyed* __restrict_
     primOrder[p] = uint32_t(slot);
 }
 
+// ---- the surface-area-heuristic variant ------------------------------------------------------------------------------
+// (reference src/bounding_volume_hierarchy.cpp:133-190; sahSplit in bvh_build.cpp.)  A node sorts its primitives on
+// x, on y, on z — each sort starting from the arrangement the one before left — prices the cuts of every sorted order,
+// and sorts once more on the axis of the cheapest cut.  The cuts depend on the data, so the tree's shape is found level
+// by level: all nodes of a level are open at once, every one of the four sorts is one run of the rounds above over
+// all of them, the boxes of all prefixes and suffixes of a sorted node are two segmented scans, and the cheapest cut of
+// a node is one 64-bit minimum over (cost, axis, position) — the order in which the sequential search keeps the first
+// of equal costs.  Nodes are created in level order with links; their depth-first numbers follow from subtree sizes
+// (bottom-up) and offsets (top-down) afterwards.
+struct SNode {
+    int first, last, level, parent;
+    int left, right, isLeaf, pad;
+    unsigned long long best; // (bits of the cost) << 32 | axis << 30 | cut position; ~0: no cut had a comparable cost
+    int sub, inner;          // nodes and inner nodes of the subtree
+    int index, innerRank;    // depth-first pre-order number; inner nodes before it in that order
+    float lo[3], hi[3];
+};
+struct SahCtl {
+    int nNodes, nOpenNext, maxCountNext, flags; // flags 4: more nodes than the table holds, 8: a cost outside the key's range
+};
+struct Box6 {
+    float lo[3], hi[3];
+};
+struct GrowBox { // Builder::grow: the earlier value stays on ties
+    __host__ __device__ Box6 operator()(const Box6& x, const Box6& y) const
+    {
+        Box6 r;
+        for (int k = 0; k < 3; k++) {
+            r.lo[k] = min_first(x.lo[k], y.lo[k]);
+            r.hi[k] = max_first(x.hi[k], y.hi[k]);
+        }
+        return r;
+    }
+};
+constexpr unsigned long long NO_CUT = ~0ull;
+constexpr int CUT_BITS = 30;
+
+__device__ __forceinline__ float box_area(const float* lo, const float* hi)
+{
+    const vec3 e = make3(hi[0], hi[1], hi[2]) - make3(lo[0], lo[1], lo[2]);
+    return dot(e, make3(e.y, e.z, e.x));
+}
+
+// Boxes of the primitives in their present arrangement, forwards and (optionally) backwards, keyed by node.
+__global__ void k_sah_gather(const Keyed* __restrict__ a, const int* __restrict__ nodeOf, const float* __restrict__ lo, const float* __restrict__ hi, Box6* __restrict__ val, int* __restrict__ key, Box6* __restrict__ valR, int* __restrict__ keyR, int n)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const size_t p = size_t(a[i].index);
+    Box6 b;
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = lo[3 * p + k];
+        b.hi[k] = hi[3 * p + k];
+    }
+    const int nd = nodeOf[i];
+    val[i] = b;
+    key[i] = nd;
+    if (valR) {
+        valR[n - 1 - i] = b;
+        keyR[n - 1 - i] = nd;
+    }
+}
+
+// Start of a level: the box of every node of the level (its primitives in the order they arrive in, as the builder's
+// bounds() walks them) from the forward scan, and the `more` counts of the slots of its leaves.
+__global__ void k_sah_node_boxes(const int* __restrict__ nodeOf, SNode* __restrict__ nodes, const Box6* __restrict__ pre, int* __restrict__ more, int n)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int nd = nodeOf[i];
+    if (nd < 0) return;
+    SNode& N = nodes[nd];
+    if (N.isLeaf) more[i] = N.last - 1 - i;
+    if (i == N.last - 1)
+        for (int k = 0; k < 3; k++) {
+            N.lo[k] = pre[i].lo[k];
+            N.hi[k] = pre[i].hi[k];
+        }
+}
+
+__device__ __forceinline__ int best_axis(unsigned long long best) { return best == NO_CUT ? 0 : int((best >> CUT_BITS) & 3ull); }
+__device__ __forceinline__ int best_cut(unsigned long long best) { return best == NO_CUT ? 0 : int(best & ((1ull << CUT_BITS) - 1ull)); }
+
+// Start of one sort of a level: keys on `axis` (or, with axis < 0, on the axis of each node's cheapest cut) and the
+// part table, one slot per node of the level (leaves and nodes of 16 primitives or fewer stay empty slots).
+__global__ void k_sah_sort_init(Keyed* __restrict__ a, const float* __restrict__ centroid, const int* __restrict__ nodeOf, const SNode* __restrict__ nodes, int* __restrict__ segOf, Seg* __restrict__ segs, int2* __restrict__ blocks, Ctl* ctl, int n, int axis, int cur, int nActive, int levelStart)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i == 0) ctl->nActive[cur] = nActive;
+    if (i >= n) return;
+    const int nd = nodeOf[i];
+    if (nd < 0 || nodes[nd].isLeaf) {
+        segOf[i] = -1;
+        return;
+    }
+    const SNode& N = nodes[nd];
+    const int count = N.last - N.first;
+    const int ax = axis >= 0 ? axis : best_axis(N.best);
+    a[i].key = centroid[3 * size_t(a[i].index) + size_t(ax)];
+    const bool active = count > SORT_THRESHOLD;
+    segOf[i] = active ? nd - levelStart : -1;
+    if (i == N.first) {
+        if (active) segs[nd - levelStart] = Seg { N.first, N.last, 2 * floor_log2(count), 0 };
+        else blocks[atomicAdd(&ctl->nBlocks[0], 1)] = make_int2(N.first, N.last);
+    }
+}
+
+// The cuts of one sorted order priced (Builder::sahSplit's `consider`).  Without binning the thread of position
+// first + k - 1 prices cut k; with binning the first `bins` threads of a node take a bin each: the cut is the number of
+// keys below the bin's boundary (at least 1), which is where the sequential search's running position stands, the
+// boundaries being non-decreasing.
+__global__ void k_sah_eval(const Keyed* __restrict__ a, const int* __restrict__ nodeOf, SNode* __restrict__ nodes, const Box6* __restrict__ pre, const Box6* __restrict__ sufR, SahCtl* sctl, int n, int axis, int bins)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int nd = nodeOf[i];
+    if (nd < 0) return;
+    const SNode& N = nodes[nd];
+    if (N.isLeaf) return;
+    const int count = N.last - N.first;
+    int k;
+    if (size_t(bins) >= size_t(count)) {
+        k = i - N.first + 1; // (cuts 0 and count have an empty side: infinite area times zero, never comparable)
+        if (k >= count) return;
+    } else {
+        const int b = i - N.first;
+        if (b >= bins) return;
+        const float c0 = a[N.first].key;
+        const float range = a[N.last - 1].key - c0;
+        const float step = range / float(bins);
+        const float boundary = c0 + float(b) * step;
+        int lo = N.first, hi = N.last; // keys below the boundary: [first, lo)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (a[mid].key < boundary) lo = mid + 1; else hi = mid;
+        }
+        k = lo - N.first;
+        if (k < 1) k = 1;
+        if (k >= count) { // (the sequential search would have run past the node's end)
+            sctl->flags = 8;
+            return;
+        }
+    }
+    const Box6& P = pre[N.first + k - 1];
+    const Box6& S = sufR[n - 1 - (N.first + k)];
+    const float invParent = 1.0f / box_area(N.lo, N.hi);
+    const float cost = (box_area(P.lo, P.hi) * float(k) + box_area(S.lo, S.hi) * float(size_t(count - k))) * invParent;
+    if (!(cost < FLT_MAX)) return;
+    const uint32_t bits = __float_as_uint(cost);
+    if (bits >> 31) { // a negative cost (or negative zero) does not order by its bits
+        sctl->flags = 8;
+        return;
+    }
+    atomicMin(&nodes[nd].best, ((unsigned long long)bits << 32) | ((unsigned long long)axis << CUT_BITS) | (unsigned long long)k);
+}
+
+// End of a level: the two children of every open node.
+__global__ void k_sah_children(SNode* __restrict__ nodes, SahCtl* sctl, int levelStart, int levelEnd, int maxLevel, int capacity)
+{
+    const int t = levelStart + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= levelEnd) return;
+    const SNode N = nodes[t];
+    if (N.isLeaf) return;
+    const int split = best_cut(N.best);
+    const int id = atomicAdd(&sctl->nNodes, 2);
+    if (id + 2 > capacity) {
+        sctl->flags = 4;
+        return;
+    }
+    for (int c = 0; c < 2; c++) {
+        SNode C;
+        C.first = c ? N.first + split : N.first;
+        C.last = c ? N.last : N.first + split;
+        C.level = N.level + 1;
+        C.parent = t;
+        C.left = C.right = -1;
+        C.isLeaf = (C.level == maxLevel || C.last - C.first <= 1) ? 1 : 0;
+        C.pad = 0;
+        C.best = NO_CUT;
+        C.sub = C.inner = C.index = C.innerRank = 0;
+        for (int k = 0; k < 3; k++) {
+            C.lo[k] = FLT_MAX;
+            C.hi[k] = -FLT_MAX;
+        }
+        nodes[id + c] = C;
+        if (!C.isLeaf) {
+            atomicAdd(&sctl->nOpenNext, 1);
+            atomicMax(&sctl->maxCountNext, C.last - C.first);
+        }
+    }
+    nodes[t].left = id;
+    nodes[t].right = id + 1;
+}
+__global__ void k_sah_assign(int* __restrict__ nodeOf, const SNode* __restrict__ nodes, int n)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    const int nd = nodeOf[i];
+    if (nd < 0) return;
+    const SNode& N = nodes[nd];
+    nodeOf[i] = N.isLeaf ? -1 : (i < N.first + best_cut(N.best) ? N.left : N.right);
+}
+
+// Subtree sizes of one level's nodes (deepest level first), then the numbers of one level's children (root first).
+__global__ void k_sah_sizes(SNode* __restrict__ nodes, int levelStart, int levelEnd)
+{
+    const int t = levelStart + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= levelEnd) return;
+    SNode& N = nodes[t];
+    N.sub = N.isLeaf ? 1 : 1 + nodes[N.left].sub + nodes[N.right].sub;
+    N.inner = N.isLeaf ? 0 : 1 + nodes[N.left].inner + nodes[N.right].inner;
+}
+__global__ void k_sah_number(SNode* __restrict__ nodes, int levelStart, int levelEnd)
+{
+    const int t = levelStart + int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= levelEnd) return;
+    const SNode& N = nodes[t];
+    if (N.isLeaf) return;
+    SNode &L = nodes[N.left], &R = nodes[N.right];
+    L.index = N.index + 1;
+    L.innerRank = N.innerRank + 1;
+    R.index = N.index + 1 + L.sub;
+    R.innerRank = N.innerRank + 1 + L.inner;
+}
+
+// Node records in the reference's order and the device table of inner nodes.
+__global__ void k_sah_write(const SNode* __restrict__ nodes, int nNodes, rt_node_record* __restrict__ refNodes, NodeRec* __restrict__ out)
+{
+    const int t = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= nNodes) return;
+    const SNode& N = nodes[t];
+    rt_node_record rec;
+    rec.is_leaf = N.isLeaf;
+    rec.level = N.level;
+    for (int k = 0; k < 3; k++) {
+        rec.lower[k] = N.lo[k];
+        rec.upper[k] = N.hi[k];
+    }
+    if (N.isLeaf) {
+        rec.a = N.first;
+        rec.b = N.last - N.first;
+    } else {
+        const SNode &L = nodes[N.left], &R = nodes[N.right];
+        rec.a = L.index;
+        rec.b = R.index;
+        NodeRec d;
+        for (int k = 0; k < 3; k++) {
+            d.boxL[2 * k] = L.lo[k]; d.boxL[2 * k + 1] = L.hi[k];
+            d.boxR[2 * k] = R.lo[k]; d.boxR[2 * k + 1] = R.hi[k];
+        }
+        d.refL = L.isLeaf ? ~L.first : L.innerRank;
+        d.refR = R.isLeaf ? ~R.first : R.innerRank;
+        d.level = N.level;
+        d.refNode = N.index;
+        out[N.innerRank] = d;
+    }
+    refNodes[N.index] = rec;
+}
+
 bool make_tables(int n, int maxLevel, Tables& T)
 {
     std::memset(&T, 0, sizeof T);
@@ -578,11 +840,15 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
         nVertices += m.vertices.size() / 8;
     }
     const size_t total = nTriangles + scene.spheres.size();
-    if (opt.sah_binning || total < 2 || total >= (size_t(1) << 28) || opt.max_level < 0 || opt.max_level >= TABLE_LEVELS - 1) return hipSuccess;
+    if (total < 2 || total >= (size_t(1) << 28) || opt.max_level < 0 || opt.max_level >= TABLE_LEVELS - 1) return hipSuccess;
+    const bool sah = opt.sah_binning != 0;
+    if (sah && opt.max_level < 1) return hipSuccess; // (the root a leaf of everything)
     const int n = int(total);
     Tables T;
-    if (!make_tables(n, opt.max_level, T)) return hipSuccess;
-    if (T.depth == opt.max_level && T.cLo[T.depth] + 1 > MAX_LEAF_PRIMS) return hipSuccess; // very large leaves: host
+    if (!sah) {
+        if (!make_tables(n, opt.max_level, T)) return hipSuccess;
+        if (T.depth == opt.max_level && T.cLo[T.depth] + 1 > MAX_LEAF_PRIMS) return hipSuccess; // very large leaves: host
+    }
     hipError_t e;
 #define RT_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
     Scratch tmp;
@@ -617,7 +883,8 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
     SegOut* segOut;
     int2 *blocks, *heaps;
     Ctl* ctl;
-    const size_t maxSegs = size_t(n) / (SORT_THRESHOLD + 1) + 2;
+    // part tables: the median variant numbers the parts of more than 16; the other has a slot per node of a level
+    const size_t maxSegs = sah ? size_t(n) + 2 : size_t(n) / (SORT_THRESHOLD + 1) + 2;
     RT_TRY(tmp.get(dLo, size_t(n) * 3));
     RT_TRY(tmp.get(dHi, size_t(n) * 3));
     RT_TRY(tmp.get(dCentroid, size_t(n) * 3));
@@ -642,73 +909,174 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
     RT_TRY(tmp.get(scanTemp, scanBytes));
     const dim3 block(256), grid(uint32_t((size_t(n) + 255) / 256));
     hipLaunchKernelGGL(k_prim_bounds, grid, block, 0, nullptr, geo, n, dLo, dHi, dCentroid, a, ctl);
-    // ---- the sorts, level by level
     int cur = 0;
     Ctl host;
-    for (int level = 0; level < T.depth; level++) {
-        const int maxCount = T.cLo[level] + 1;
-        const int nActive = maxCount > SORT_THRESHOLD ? (1 << level) : 0; // (then every node of the level exists)
-        if (size_t(nActive) > maxSegs) return hipErrorInvalidValue;       // cannot happen: 2^level parts of more than 16
-        hipLaunchKernelGGL(k_level_init, grid, block, 0, nullptr, a, dCentroid, segOf, segs[cur], blocks, ctl, n, level, cur, nActive);
-        if (nActive > 0) {
-            // introsort needs about 1.4 log2(count / 16) partitions of a part; the rounds are launched in batches and the
-            // number of parts still active is read back after each
-            int batch = 2;
-            for (int c = maxCount; c > SORT_THRESHOLD; c >>= 1) batch += (batch & 1) ? 2 : 1;
-            while (true) {
-                for (int r = 0; r < batch; r++) {
-                    hipLaunchKernelGGL(k_round_flags, grid, block, 0, nullptr, a, segOf, segs[cur], flags, ctl, n, cur);
-                    RT_TRY(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, flags, scan, n + 1, nullptr));
-                    hipLaunchKernelGGL(k_round_ranks, grid, block, 0, nullptr, a, segOf, segs[cur], scan, posL, posR, ctl, n, cur);
-                    hipLaunchKernelGGL(k_round_cuts, dim3(uint32_t((maxSegs + 255) / 256)), block, 0, nullptr, segs[cur], segs[cur ^ 1], segOut, scan, posL, posR, blocks, heaps, ctl, level, cur);
-                    hipLaunchKernelGGL(k_round_swaps, grid, block, 0, nullptr, a, segOf, segs[cur], segOut, scan, posR, ctl, n, cur);
-                    cur ^= 1;
-                }
-                RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
-                RT_TRY(hipStreamSynchronize(nullptr));
-                if (host.flags) return hipSuccess; // unsupported: a NaN key, or too much for the heapsort kernel
-                if (host.nActive[cur] == 0) break;
-                batch = 3;
+    bool giveUp = false; // a NaN key, or too much for the heapsort kernel: the host builds
+    // The rounds of one sort over the part table segs[cur] (counters of slot `slot`), then its heap sorts.  introsort
+    // needs about 1.4 log2(count / 16) partitions of a part; the rounds are launched in batches and the number of parts
+    // still active is read back after each.
+    auto run_rounds = [&](int slot, int maxCount) -> hipError_t {
+        int batch = 2;
+        for (int c = maxCount; c > SORT_THRESHOLD; c >>= 1) batch += (batch & 1) ? 2 : 1;
+        while (true) {
+            for (int r = 0; r < batch; r++) {
+                hipLaunchKernelGGL(k_round_flags, grid, block, 0, nullptr, a, segOf, segs[cur], flags, ctl, n, cur);
+                RT_TRY(hipcub::DeviceScan::ExclusiveSum(scanTemp, scanBytes, flags, scan, n + 1, nullptr));
+                hipLaunchKernelGGL(k_round_ranks, grid, block, 0, nullptr, a, segOf, segs[cur], scan, posL, posR, ctl, n, cur);
+                hipLaunchKernelGGL(k_round_cuts, dim3(uint32_t((maxSegs + 255) / 256)), block, 0, nullptr, segs[cur], segs[cur ^ 1], segOut, scan, posL, posR, blocks, heaps, ctl, slot, cur);
+                hipLaunchKernelGGL(k_round_swaps, grid, block, 0, nullptr, a, segOf, segs[cur], segOut, scan, posR, ctl, n, cur);
+                cur ^= 1;
             }
-            hipLaunchKernelGGL(k_heap_sorts, dim3(MAX_HEAP_PARTS / 256), block, 0, nullptr, a, heaps, ctl, level);
+            RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+            RT_TRY(hipStreamSynchronize(nullptr));
+            if (host.flags) {
+                giveUp = true;
+                return hipSuccess;
+            }
+            if (host.nActive[cur] == 0) break;
+            batch = 3;
         }
-        hipLaunchKernelGGL(k_sort_blocks, grid, block, 0, nullptr, a, blocks, ctl, level);
-    }
-    RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
-    RT_TRY(hipStreamSynchronize(nullptr));
-    if (host.flags) return hipSuccess;
-    // ---- nodes, boxes, device tables
-    out.numRefNodes = size_t(T.sub[0][n - T.cLo[0]]);
-    out.numInner = size_t(T.inner[0][n - T.cLo[0]]);
-    out.numLeaves = T.leaves[0][n - T.cLo[0]];
-    out.numLevels = T.depth + 1;
-    out.numPrims = size_t(n);
+        hipLaunchKernelGGL(k_heap_sorts, dim3(MAX_HEAP_PARTS / 256), block, 0, nullptr, a, heaps, ctl, slot);
+        return hipSuccess;
+    };
     struct Guard {
         DeviceBvh& d;
         bool keep = false;
         ~Guard() { if (!keep) d.release(); }
     } guard { out };
-    RT_TRY(own(out.nodes, out.numInner));
+    out.numPrims = size_t(n);
+    if (!sah) {
+        // ---- the sorts, level by level
+        for (int level = 0; level < T.depth; level++) {
+            const int maxCount = T.cLo[level] + 1;
+            const int nActive = maxCount > SORT_THRESHOLD ? (1 << level) : 0; // (then every node of the level exists)
+            if (size_t(nActive) > maxSegs) return hipErrorInvalidValue;       // cannot happen: 2^level parts of more than 16
+            hipLaunchKernelGGL(k_level_init, grid, block, 0, nullptr, a, dCentroid, segOf, segs[cur], blocks, ctl, n, level, cur, nActive);
+            if (nActive > 0) {
+                RT_TRY(run_rounds(level, maxCount));
+                if (giveUp) return hipSuccess;
+            }
+            hipLaunchKernelGGL(k_sort_blocks, grid, block, 0, nullptr, a, blocks, ctl, level);
+        }
+        RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+        RT_TRY(hipStreamSynchronize(nullptr));
+        if (host.flags) return hipSuccess;
+        // ---- nodes, boxes, device tables
+        out.numRefNodes = size_t(T.sub[0][n - T.cLo[0]]);
+        out.numInner = size_t(T.inner[0][n - T.cLo[0]]);
+        out.numLeaves = T.leaves[0][n - T.cLo[0]];
+        out.numLevels = T.depth + 1;
+        RT_TRY(own(out.nodes, out.numInner));
+        RT_TRY(own(out.refNodes, out.numRefNodes));
+        const unsigned long long heap = (2ull << T.depth) - 1ull; // threads of the per-node kernels: every (level, path)
+        const dim3 gridNodes(uint32_t((heap + 255) / 256));
+        hipLaunchKernelGGL(k_nodes, gridNodes, block, 0, nullptr, T, a, dLo, dHi, out.refNodes, more);
+        for (int level = T.depth - 1; level >= 0; level--)
+            hipLaunchKernelGGL(k_boxes, dim3(uint32_t(((1ull << level) + 255) / 256)), block, 0, nullptr, T, level, out.refNodes);
+        hipLaunchKernelGGL(k_flatten, gridNodes, block, 0, nullptr, T, out.refNodes, out.nodes);
+    } else {
+        // ---- the tree, level by level
+        const int capacity = 4 * n + 64; // (2 n - 1 nodes unless cuts at position 0 leave empty leaves behind)
+        SNode* nodes;
+        SahCtl* sctl;
+        int *nodeOf, *key, *keyR;
+        Box6 *val, *valR, *pre, *sufR;
+        RT_TRY(tmp.get(nodes, size_t(capacity)));
+        RT_TRY(tmp.get(sctl, 1));
+        RT_TRY(tmp.get(nodeOf, size_t(n)));
+        RT_TRY(tmp.get(key, size_t(n)));
+        RT_TRY(tmp.get(keyR, size_t(n)));
+        RT_TRY(tmp.get(val, size_t(n)));
+        RT_TRY(tmp.get(valR, size_t(n)));
+        RT_TRY(tmp.get(pre, size_t(n)));
+        RT_TRY(tmp.get(sufR, size_t(n)));
+        size_t boxScanBytes = 0;
+        RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, boxScanBytes, key, val, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+        char* boxScanTemp;
+        RT_TRY(tmp.get(boxScanTemp, boxScanBytes));
+        SNode root;
+        std::memset(&root, 0, sizeof root);
+        root.last = n;
+        root.parent = root.left = root.right = -1;
+        root.best = NO_CUT;
+        for (int k = 0; k < 3; k++) {
+            root.lo[k] = FLT_MAX;
+            root.hi[k] = -FLT_MAX;
+        }
+        SahCtl sh { 1, 1, n, 0 };
+        RT_TRY(hipMemcpyAsync(nodes, &root, sizeof root, hipMemcpyHostToDevice, nullptr));
+        RT_TRY(hipMemcpyAsync(sctl, &sh, sizeof sh, hipMemcpyHostToDevice, nullptr));
+        RT_TRY(hipMemsetAsync(nodeOf, 0, size_t(n) * sizeof(int), nullptr));
+        std::vector<int> levelStart { 0, 1 }; // nodes of level l: [levelStart[l], levelStart[l + 1])
+        for (int level = 0;; level++) {
+            const int first = levelStart[size_t(level)], end = levelStart[size_t(level) + 1];
+            const int nOpen = sh.nOpenNext, maxCount = sh.maxCountNext;
+            hipLaunchKernelGGL(k_sah_gather, grid, block, 0, nullptr, a, nodeOf, dLo, dHi, val, key, (Box6*)nullptr, (int*)nullptr, n);
+            RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, key, val, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+            hipLaunchKernelGGL(k_sah_node_boxes, grid, block, 0, nullptr, nodeOf, nodes, pre, more, n);
+            if (nOpen == 0) break;
+            if (size_t(end - first) > maxSegs) return hipErrorInvalidValue; // cannot happen: a level's nodes have n primitives
+            const int nActive = maxCount > SORT_THRESHOLD ? end - first : 0;
+            for (int pass = 0; pass < 4; pass++) { // x, y, z, and the axis of the cheapest cut
+                RT_TRY(hipMemsetAsync(&ctl->nBlocks[0], 0, sizeof(int), nullptr));
+                RT_TRY(hipMemsetAsync(&ctl->nHeaps[0], 0, sizeof(int), nullptr));
+                if (nActive > 0) RT_TRY(hipMemsetAsync(segs[cur], 0, size_t(nActive) * sizeof(Seg), nullptr));
+                hipLaunchKernelGGL(k_sah_sort_init, grid, block, 0, nullptr, a, dCentroid, nodeOf, nodes, segOf, segs[cur], blocks, ctl, n, pass < 3 ? pass : -1, cur, nActive, first);
+                if (nActive > 0) {
+                    RT_TRY(run_rounds(0, maxCount));
+                    if (giveUp) return hipSuccess;
+                }
+                hipLaunchKernelGGL(k_sort_blocks, grid, block, 0, nullptr, a, blocks, ctl, 0);
+                if (pass == 3) break;
+                hipLaunchKernelGGL(k_sah_gather, grid, block, 0, nullptr, a, nodeOf, dLo, dHi, val, key, valR, keyR, n);
+                RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, key, val, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+                RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, keyR, valR, sufR, GrowBox(), n, hipcub::Equality(), nullptr));
+                hipLaunchKernelGGL(k_sah_eval, grid, block, 0, nullptr, a, nodeOf, nodes, pre, sufR, sctl, n, pass, opt.sah_bins);
+            }
+            RT_TRY(hipMemsetAsync(&sctl->nOpenNext, 0, 2 * sizeof(int), nullptr));
+            hipLaunchKernelGGL(k_sah_children, dim3(uint32_t((size_t(end - first) + 255) / 256)), block, 0, nullptr, nodes, sctl, first, end, opt.max_level, capacity);
+            hipLaunchKernelGGL(k_sah_assign, grid, block, 0, nullptr, nodeOf, nodes, n);
+            RT_TRY(hipMemcpyAsync(&sh, sctl, sizeof sh, hipMemcpyDeviceToHost, nullptr));
+            RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+            RT_TRY(hipStreamSynchronize(nullptr));
+            if (sh.flags || host.flags) return hipSuccess;
+            levelStart.push_back(sh.nNodes);
+        }
+        RT_TRY(hipMemcpyAsync(&host, ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+        RT_TRY(hipStreamSynchronize(nullptr));
+        if (host.flags) return hipSuccess;
+        // ---- numbers and tables
+        const int numLevels = int(levelStart.size()) - 1, nNodes = levelStart.back();
+        auto launch_level = [&](void (*kernel)(SNode*, int, int), int level) {
+            const int first = levelStart[size_t(level)], end = levelStart[size_t(level) + 1];
+            if (end > first) hipLaunchKernelGGL(kernel, dim3(uint32_t((size_t(end - first) + 255) / 256)), block, 0, nullptr, nodes, first, end);
+        };
+        for (int level = numLevels - 1; level >= 0; level--) launch_level(k_sah_sizes, level);
+        for (int level = 0; level < numLevels - 1; level++) launch_level(k_sah_number, level);
+        RT_TRY(hipMemcpyAsync(&root, nodes, sizeof root, hipMemcpyDeviceToHost, nullptr));
+        RT_TRY(hipStreamSynchronize(nullptr));
+        if (root.sub != nNodes) return hipErrorInvalidValue;
+        out.numRefNodes = size_t(nNodes);
+        out.numInner = size_t(root.inner);
+        out.numLeaves = nNodes - root.inner;
+        out.numLevels = numLevels;
+        RT_TRY(own(out.nodes, out.numInner));
+        RT_TRY(own(out.refNodes, out.numRefNodes));
+        hipLaunchKernelGGL(k_sah_write, dim3(uint32_t((size_t(nNodes) + 255) / 256)), block, 0, nullptr, nodes, nNodes, out.refNodes, out.nodes);
+    }
     RT_TRY(own(out.prims, out.numPrims));
     RT_TRY(own(out.attrs, out.numPrims));
     RT_TRY(own(out.primOrder, out.numPrims));
-    RT_TRY(own(out.refNodes, out.numRefNodes));
     RT_TRY(own(out.refPrims, out.numPrims));
-    const unsigned long long heap = (2ull << T.depth) - 1ull; // threads of the per-node kernels: every (level, path)
-    const dim3 gridNodes(uint32_t((heap + 255) / 256));
-    hipLaunchKernelGGL(k_nodes, gridNodes, block, 0, nullptr, T, a, dLo, dHi, out.refNodes, more);
-    for (int level = T.depth - 1; level >= 0; level--)
-        hipLaunchKernelGGL(k_boxes, dim3(uint32_t(((1ull << level) + 255) / 256)), block, 0, nullptr, T, level, out.refNodes);
-    hipLaunchKernelGGL(k_flatten, gridNodes, block, 0, nullptr, T, out.refNodes, out.nodes);
     hipLaunchKernelGGL(k_prim_records, grid, block, 0, nullptr, geo, n, a, more, out.prims, out.attrs, out.refPrims, out.primOrder);
     RT_TRY(hipGetLastError());
-    rt_node_record root;
-    RT_TRY(hipMemcpyAsync(&root, out.refNodes, sizeof root, hipMemcpyDeviceToHost, nullptr));
+    rt_node_record rootRec;
+    RT_TRY(hipMemcpyAsync(&rootRec, out.refNodes, sizeof rootRec, hipMemcpyDeviceToHost, nullptr));
     RT_TRY(hipStreamSynchronize(nullptr));
 #undef RT_TRY
-    std::memcpy(out.rootLo, root.lower, 12);
-    std::memcpy(out.rootHi, root.upper, 12);
-    out.rootRef = root.is_leaf ? ~root.a : 0;
+    std::memcpy(out.rootLo, rootRec.lower, 12);
+    std::memcpy(out.rootHi, rootRec.upper, 12);
+    out.rootRef = rootRec.is_leaf ? ~rootRec.a : 0;
     guard.keep = true;
     unsupported = false;
     return hipSuccess;
