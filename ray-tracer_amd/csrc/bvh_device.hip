@@ -976,7 +976,10 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
         hipLaunchKernelGGL(k_flatten, gridNodes, block, 0, nullptr, T, out.refNodes, out.nodes);
     } else {
         // ---- the tree, level by level
-        const int capacity = 4 * n + 64; // (2 n - 1 nodes unless cuts at position 0 leave empty leaves behind)
+        // 2 n - 1 nodes, unless nodes without area cut at position 0 and leave an empty leaf behind on every level down to
+        // the limit: a level has n nodes at most, which small scenes are given room for; beyond the table the host builds
+        const long long worst = (long long)n * (opt.max_level + 1) + 1;
+        const int capacity = int(std::max<long long>(4ll * n + 64, std::min<long long>(worst, 1ll << 18)));
         SNode* nodes;
         SahCtl* sctl;
         int *nodeOf, *key, *keyR;

@@ -209,6 +209,36 @@ def test_sah_trees_with_level_limits_several_meshes_and_spheres(lib):
         _check_sah(lib, sc, max_level=max_level, sah_bins=3)
 
 
+def _soup(n, rng, grid):
+    """n triangles with vertices on a coarse grid (grid + 1 values per axis): equal centroids, equal boxes, flat and
+    degenerate triangles, duplicates."""
+    pos = rng.integers(0, grid + 1, size=(3 * n, 3)).astype(np.float32) / np.float32(grid) - np.float32(0.5)
+    v = np.zeros((3 * n, 8), dtype=np.float32)
+    v[:, :3] = pos
+    v[:, 4] = 1.0
+    tris = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    return dict(vertices=v, triangles=tris, kd=(0.8, 0.8, 0.8), ks=(0.2, 0.2, 0.2), shininess=20.0, transparency=1.0, texture=-1)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_triangle_soups_on_a_coarse_grid_both_variants(lib, seed):
+    """Sizes around the sort's threshold of 16 and the bin count, coordinates from a handful of values: ties in every
+    sort, equal costs among cuts, nodes without area."""
+    synth = importlib.import_module("ray-tracer_amd.synth")
+    rng = np.random.default_rng(100 + seed)
+    for n in (2, 3, 15, 16, 17, 18, 31, 33, 63, 64, 65, 66, 130, 257, 1000):
+        sc = rt.SceneData([_soup(n, rng, int(rng.integers(1, 9)))], lights=synth.area_light())
+        sh = lib.scene_create(sc)
+        for options in (dict(), dict(sah=True), dict(sah=True, sah_bins=int(rng.integers(1, 70))), dict(sah=True, max_level=int(rng.integers(1, 12))),
+                        dict(max_level=int(rng.integers(3, 12)))):
+            host = lib.bvh_build(sh, **options)
+            dev, on_device = lib.bvh_build_device(sh, **options)
+            assert _same_tree(lib, host, dev), (n, options)
+            assert on_device or (not options.get("sah") and "max_level" in options), (n, options)
+            lib.lib.rt_bvh_destroy(host)
+            lib.lib.rt_bvh_destroy(dev)
+
+
 @pytest.mark.parametrize("level,symmetric", [(7, False), (8, False), (8, True)])
 def test_large_meshes_same_tree_and_build_time(lib, level, symmetric):
     """327,680 and 1,310,720 triangles.  At this size float coordinates collide by the thousand, a few of them at cuts
