@@ -11,7 +11,12 @@ sc = rt.SceneData([synth.dragon_class_mesh(level)], lights=synth.area_light())
 sh = lib.scene_create(sc)
 t0 = time.perf_counter(); host = lib.bvh_build(sh, sah=sah); t1 = time.perf_counter()
 print(f"{sc.n_triangles} triangles{', SAH with 64 bins' if sah else ''}: host build {t1 - t0:.3f} s", flush=True)
+import numpy as np
+hn, hp = lib.bvh_export(host)
 for i in range(3):
     t0 = time.perf_counter(); dev, on = lib.bvh_build_device(sh, sah=sah); t1 = time.perf_counter()
     print(f"  rt_bvh_build_device call {i}: {t1 - t0:.4f} s (on the GPU: {on})", flush=True)
+    if i == 0:
+        dn, dp = lib.bvh_export(dev)
+        print(f"  same tree as the host's: {np.array_equal(hn, dn) and np.array_equal(hp, dp)} ({len(hn)} nodes, {lib.lib.rt_bvh_num_levels(dev)} levels)", flush=True)
     lib.lib.rt_bvh_destroy(dev)
