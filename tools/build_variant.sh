@@ -9,6 +9,6 @@ OUT=$ROOT/build_variants
 mkdir -p $OUT
 make -s -C $SRC
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -I$ROOT/include -I$SRC $2 -c $SRC/rt_kernels.hip -o $OUT/rt_kernels_$1.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/librt_amd_$1.so $OUT/rt_kernels_$1.o $SRC/_obj/rt_api.o $SRC/_obj/bvh_build.o $SRC/_obj/bvh_device.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/librt_amd_$1.so $OUT/rt_kernels_$1.o $SRC/_obj/rt_api.o $SRC/_obj/bvh_build.o $SRC/_obj/bvh_device.o $SRC/_obj/rt_comm.o -ldl
 rm -f $OUT/rt_kernels_$1.o
 echo built $OUT/librt_amd_$1.so
