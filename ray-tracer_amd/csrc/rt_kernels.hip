@@ -138,8 +138,12 @@ __device__ __forceinline__ float* hit_colour_slot(const FrameParams& P, uint32_t
 //   k_closest   the unbudgeted traversal for the few queued rays that do meet something.
 // A miss is final (sky or black); a hit goes to the hit queue, appended with one atomic per wave so that the hits
 // of a tile stay together.
-template <bool PRUNE, bool COUNT>
-__global__ void __launch_bounds__(WAVE) k_primary(const FrameParams P)
+// WAVES per SIMD: the pass is bound by the latency of a ray's chain of node visits, which more waves hide — eight of
+// them (64 registers, a handful spilled) take the camera pass of the 1080p soft-shadow frame from 1.64 to 1.54 ms;
+// with an environment map the rays that miss need the registers more (Monkey frame 0.65 -> 0.80 ms), and so do lens
+// rays (4K depth-of-field frame +0.8 %): seven there.
+template <bool PRUNE, bool COUNT, int WAVES>
+__global__ void __launch_bounds__(WAVE, WAVES) k_primary(const FrameParams P)
 {
     extern __shared__ uint2 lds_stack[];
     Stack st { lds_stack + threadIdx.x, uint32_t(WAVE) };
@@ -1690,8 +1694,9 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
     const size_t streamLds = stream_lds_bytes(P.pairStackLds);
     {
         // enough chunks for every resident wave to come back to the cursor several times
-        const uint32_t waves = P.countTests ? resident_blocks(k_primary<PRUNE, true>, WAVE, size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2))
-                                            : resident_blocks(k_primary<PRUNE, false>, WAVE, size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2));
+        const bool sky = P.f.environment_mapping != 0 || P.f.depth_of_field != 0; // (the kernel's variants with more live registers)
+        const auto kernel = P.countTests ? (sky ? k_primary<PRUNE, true, 7> : k_primary<PRUNE, true, 8>) : (sky ? k_primary<PRUNE, false, 7> : k_primary<PRUNE, false, 8>);
+        const uint32_t waves = resident_blocks(kernel, WAVE, size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2));
         uint32_t chunk = P.logicalBlocks / (waves * 8u);
         chunk = chunk < 1u ? 1u : (chunk > PRIMARY_CHUNK_MAX ? PRIMARY_CHUNK_MAX : chunk);
         FrameParams Q = P;
@@ -1702,8 +1707,7 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
         // the pass (measured: 1/8 of the headline frame 1.18 -> 1.00 ms), with many it only moves work to the
         // kernels behind (whole frame 2.69 -> 3.59 ms).
         if (P.logicalBlocks < waves * uint32_t(P.primarySmallPass) && Q.primaryBudget > 32) Q.primaryBudget = 32;
-        if (Q.countTests) launch_walkers(k_primary<PRUNE, true>, Q, ldsPrimary, stream);
-        else launch_walkers(k_primary<PRUNE, false>, Q, ldsPrimary, stream);
+        launch_walkers(kernel, Q, ldsPrimary, stream);
     }
     auto finish_gave_up = [&](hipStream_t st) {
         // how many rays gave up, and how many of those meet a primitive, is only known on the device: both kernels
