@@ -1014,8 +1014,9 @@ __global__ void __launch_bounds__(WAVE, 5) k_stream(const FrameParams P)
 }
 
 // Shade pass: one lane per queued hit — direct lighting with the visibility bits of the shadow pass
-// (reference src/light.cpp:124-220 for a hit whose colour is Lo, src/render.cpp:64-67).
-__global__ void __launch_bounds__(BLOCK) k_shade(const FrameParams P)
+// (reference src/light.cpp:124-220 for a hit whose colour is Lo, src/render.cpp:64-67).  Eight waves per SIMD (64
+// registers): the pass waits on the hit, material and visibility reads of its lanes (0.33 -> 0.30 ms).
+__global__ void __launch_bounds__(BLOCK, 8) k_shade(const FrameParams P)
 {
     const unsigned int qBegin = (unsigned int)P.queueCounters[Q_RANGE_BEGIN], nHits = (unsigned int)P.queueCounters[Q_RANGE_END];
     const uint32_t nPix = uint32_t(size_t(P.rowsLocal) * size_t(P.width));
