@@ -559,6 +559,7 @@ rt_status rt_bvh_build_device(rt_scene* scene, const rt_bvh_options* options, rt
     rt_bvh_options opt { 0, 32, 64 };
     if (options) opt = *options;
     if (opt.max_level < 0 || opt.max_level > RT_MAX_LEVELS - 1) return fail(RT_ERR_LIMIT, "max_level must be in [0, 32]");
+    if (opt.sah_binning && opt.sah_bins < 1) return fail(RT_ERR_INVALID, "sah_bins must be positive");
     // the scene's own tables first: that also fixes the device the scene (and this hierarchy) lives on
     rt_status st = upload_scene(scene);
     if (st != RT_OK) return st;
@@ -567,7 +568,12 @@ rt_status rt_bvh_build_device(rt_scene* scene, const rt_bvh_options* options, rt
     bool unsupported = true;
     try {
         const hipError_t e = device_build(scene->host, opt, dev, unsupported);
-        if (e != hipSuccess) {
+        if (e == hipErrorOutOfMemory) {
+            // no room for the builder's working tables beside what the device already holds: the host builds
+            dev.release();
+            (void)hipGetLastError();
+            unsupported = true;
+        } else if (e != hipSuccess) {
             dev.release();
             return hip_fail(e, "rt_bvh_build_device");
         }

@@ -163,8 +163,13 @@ def test_gpu_only_entry_points_fail_cleanly_without_a_gpu(lib):
     assert lib.lib.rt_comm_init_rank(None, 0, 1, None) == 1
     assert lib.lib.rt_render_blocks_gather(None, None, None, 0, None, None, 4, 4, 16, None, 0, None, 0, None, None) == 1
     lib.lib.rt_comm_destroy(None)
+    sc = rt.SceneData.from_golden(o.golden("cornell"))
+    for build in (lib.bvh_build, lib.bvh_build_device):  # the same refusals from both builders
+        with pytest.raises(rt.RtError, match="sah_bins must be positive"):
+            build(lib.scene_create(sc), sah=True, sah_bins=0)
+        with pytest.raises(rt.RtError, match="max_level"):
+            build(lib.scene_create(sc), max_level=33)
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the GPU tests cover the working paths")
-    sc = rt.SceneData.from_golden(o.golden("cornell"))
     with pytest.raises(rt.RtError):
         lib.bvh_build_device(lib.scene_create(sc))
