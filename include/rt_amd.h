@@ -205,7 +205,7 @@ rt_status rt_bvh_build(rt_scene* scene, const rt_bvh_options* options, rt_bvh** 
  * boxes and the device tables, without a round trip through host memory (1.31 M triangles: median variant 0.03 s
  * against 0.47 s on 16 host threads, SAH variant with 64 bins 0.13 s against 1.9 s).  The hierarchy lives on the
  * device that is current at the call.  Falls back to rt_bvh_build for scenes of fewer than two primitives, NaN
- * coordinates and, in the median variant, leaves of more than 64 primitives (max_level cutting the tree short).
+ * coordinates, and when the device has no room for the builder's working tables.
  * rt_bvh_device_sorted tells which way a hierarchy was built (1 = on the GPU). */
 rt_status rt_bvh_build_device(rt_scene* scene, const rt_bvh_options* options, rt_bvh** out);
 int32_t rt_bvh_device_sorted(const rt_bvh* bvh);

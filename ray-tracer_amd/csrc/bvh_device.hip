@@ -26,8 +26,9 @@
 // With the median cut the node ranges of every level follow from the primitive count alone (counts of a level differ
 // by at most one), so node numbers (depth-first pre-order, as the reference appends them), leaf slots and inner-node
 // ranks are closed-form from per-level tables of subtree sizes, and every node can be written by a thread of its own.
-// Boxes are combined bottom-up, a level per launch, left before right and keeping the earlier value on ties — which is
-// what the host builder's sequential fmin / fmax over the node's primitives yields (signed zeros included).
+// A leaf's box is a segmented scan over its primitives' boxes in order; inner boxes are combined bottom-up, a level per
+// launch, left before right and keeping the earlier value on ties — which is what the host builder's sequential
+// fmin / fmax over the node's primitives yields (signed zeros included).
 //
 // The surface-area-heuristic variant (src/bounding_volume_hierarchy.cpp:133-190) runs on the same sorts; its part of
 // this file says how the cuts are found and the nodes numbered when the tree's shape depends on the data.
@@ -47,7 +48,6 @@ namespace {
 
 constexpr int SORT_THRESHOLD = 16; // libstdc++'s _S_threshold
 constexpr int TABLE_LEVELS = 34;
-constexpr int MAX_LEAF_PRIMS = 64; // leaves cut off by the level limit: a thread walks its leaf's primitives
 
 struct Keyed {
     float key;
@@ -85,6 +85,47 @@ struct Geometry {
     const rt_sphere_desc* spheres;
     int nMeshes, nTriangles, nSpheres;
 };
+
+// A box as the segmented scans carry it, and their operator.
+struct Box6 {
+    float lo[3], hi[3];
+};
+struct GrowBox { // Builder::grow: the earlier value stays on ties
+    __host__ __device__ Box6 operator()(const Box6& x, const Box6& y) const
+    {
+        Box6 r;
+        for (int k = 0; k < 3; k++) {
+            r.lo[k] = min_first(x.lo[k], y.lo[k]);
+            r.hi[k] = max_first(x.hi[k], y.hi[k]);
+        }
+        return r;
+    }
+};
+// Inputs of the box scans, made on the fly: position -> box of the primitive that stands there, and -> key of the
+// position; reversed, both read position n - 1 - i (a scan from the end).
+struct BoxAt {
+    const Keyed* a;
+    const float *lo, *hi;
+    int n, reversed;
+    __host__ __device__ Box6 operator()(int i) const
+    {
+        const size_t p = size_t(a[reversed ? n - 1 - i : i].index);
+        Box6 b;
+        for (int k = 0; k < 3; k++) {
+            b.lo[k] = lo[3 * p + k];
+            b.hi[k] = hi[3 * p + k];
+        }
+        return b;
+    }
+};
+struct KeyAt {
+    const int* key;
+    int n, reversed;
+    __host__ __device__ int operator()(int i) const { return key[reversed ? n - 1 - i : i]; }
+};
+using Positions = hipcub::CountingInputIterator<int>;
+using BoxIterator = hipcub::TransformInputIterator<Box6, BoxAt, Positions>;
+using KeyIterator = hipcub::TransformInputIterator<int, KeyAt, Positions>;
 
 __device__ __forceinline__ int mesh_of(const Geometry& g, int prim)
 {
@@ -397,9 +438,27 @@ __device__ __forceinline__ bool node_of_thread(const Tables& T, NodeAt& nd)
     return node_at(T, level, uint32_t(t - (1ull << level)), nd);
 }
 
-// Every node's record in the reference's order; leaves with their box (their primitives in order, as the builder's
-// bounds() walks them) and the `more` counts of their slots.
-__global__ void k_nodes(const Tables T, const Keyed* __restrict__ a, const float* __restrict__ lo, const float* __restrict__ hi, rt_node_record* __restrict__ nodes, int* __restrict__ more)
+// The leaf of every position (halving [0, n) until a node has one primitive or stands on the level limit): the `more`
+// count of the slot, and the leaf's first position as the key of the box scan below.
+__global__ void k_leaf_of(const Tables T, int* __restrict__ more, int* __restrict__ key)
+{
+    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= T.n) return;
+    int first = 0, count = T.n;
+    for (int l = 0; l < T.maxLevel && count > 1; l++) {
+        const int left = count / 2;
+        if (i < first + left) {
+            count = left;
+        } else {
+            first += left;
+            count -= left;
+        }
+    }
+    more[i] = first + count - 1 - i;
+    key[i] = first;
+}
+// Every node's record in the reference's order; a leaf's box is the scanned box at its last position.
+__global__ void k_nodes(const Tables T, const Box6* __restrict__ pre, rt_node_record* __restrict__ nodes)
 {
     NodeAt nd;
     if (!node_of_thread(T, nd)) return;
@@ -413,13 +472,12 @@ __global__ void k_nodes(const Tables T, const Keyed* __restrict__ a, const float
     if (nd.leaf) {
         rec.a = nd.first;
         rec.b = nd.count;
-        for (int j = 0; j < nd.count; j++) {
-            const size_t p = size_t(a[nd.first + j].index);
+        if (nd.count > 0) {
+            const Box6& b = pre[nd.first + nd.count - 1];
             for (int k = 0; k < 3; k++) {
-                rec.lower[k] = min_first(rec.lower[k], lo[3 * p + k]);
-                rec.upper[k] = max_first(rec.upper[k], hi[3 * p + k]);
+                rec.lower[k] = b.lo[k];
+                rec.upper[k] = b.hi[k];
             }
-            more[nd.first + j] = nd.count - 1 - j;
         }
     } else {
         rec.a = nd.index + 1;
@@ -525,20 +583,6 @@ struct SNode {
 struct SahCtl {
     int nNodes, nOpenNext, maxCountNext, flags; // flags 4: more nodes than the table holds, 8: a cost outside the key's range
 };
-struct Box6 {
-    float lo[3], hi[3];
-};
-struct GrowBox { // Builder::grow: the earlier value stays on ties
-    __host__ __device__ Box6 operator()(const Box6& x, const Box6& y) const
-    {
-        Box6 r;
-        for (int k = 0; k < 3; k++) {
-            r.lo[k] = min_first(x.lo[k], y.lo[k]);
-            r.hi[k] = max_first(x.hi[k], y.hi[k]);
-        }
-        return r;
-    }
-};
 constexpr unsigned long long NO_CUT = ~0ull;
 constexpr int CUT_BITS = 30;
 
@@ -546,26 +590,6 @@ __device__ __forceinline__ float box_area(const float* lo, const float* hi)
 {
     const vec3 e = make3(hi[0], hi[1], hi[2]) - make3(lo[0], lo[1], lo[2]);
     return dot(e, make3(e.y, e.z, e.x));
-}
-
-// Boxes of the primitives in their present arrangement, forwards and (optionally) backwards, keyed by node.
-__global__ void k_sah_gather(const Keyed* __restrict__ a, const int* __restrict__ nodeOf, const float* __restrict__ lo, const float* __restrict__ hi, Box6* __restrict__ val, int* __restrict__ key, Box6* __restrict__ valR, int* __restrict__ keyR, int n)
-{
-    const int i = int(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= n) return;
-    const size_t p = size_t(a[i].index);
-    Box6 b;
-    for (int k = 0; k < 3; k++) {
-        b.lo[k] = lo[3 * p + k];
-        b.hi[k] = hi[3 * p + k];
-    }
-    const int nd = nodeOf[i];
-    val[i] = b;
-    key[i] = nd;
-    if (valR) {
-        valR[n - 1 - i] = b;
-        keyR[n - 1 - i] = nd;
-    }
 }
 
 // Start of a level: the box of every node of the level (its primitives in the order they arrive in, as the builder's
@@ -847,7 +871,6 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
     Tables T;
     if (!sah) {
         if (!make_tables(n, opt.max_level, T)) return hipSuccess;
-        if (T.depth == opt.max_level && T.cLo[T.depth] + 1 > MAX_LEAF_PRIMS) return hipSuccess; // very large leaves: host
     }
     hipError_t e;
 #define RT_TRY(call) do { if ((e = (call)) != hipSuccess) return e; } while (0)
@@ -968,9 +991,21 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
         out.numLevels = T.depth + 1;
         RT_TRY(own(out.nodes, out.numInner));
         RT_TRY(own(out.refNodes, out.numRefNodes));
+        // leaf boxes: a segmented scan over the primitives' boxes in their final order, one segment per leaf (the keys
+        // take the place of the sorts' part numbers, which nobody needs any more)
+        Box6* pre;
+        RT_TRY(tmp.get(pre, size_t(n)));
+        const KeyIterator keys(Positions(0), KeyAt { segOf, n, 0 });
+        const BoxIterator boxes(Positions(0), BoxAt { a, dLo, dHi, n, 0 });
+        size_t boxScanBytes = 0;
+        RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, boxScanBytes, keys, boxes, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+        char* boxScanTemp;
+        RT_TRY(tmp.get(boxScanTemp, boxScanBytes));
+        hipLaunchKernelGGL(k_leaf_of, grid, block, 0, nullptr, T, more, segOf);
+        RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, keys, boxes, pre, GrowBox(), n, hipcub::Equality(), nullptr));
         const unsigned long long heap = (2ull << T.depth) - 1ull; // threads of the per-node kernels: every (level, path)
         const dim3 gridNodes(uint32_t((heap + 255) / 256));
-        hipLaunchKernelGGL(k_nodes, gridNodes, block, 0, nullptr, T, a, dLo, dHi, out.refNodes, more);
+        hipLaunchKernelGGL(k_nodes, gridNodes, block, 0, nullptr, T, pre, out.refNodes);
         for (int level = T.depth - 1; level >= 0; level--)
             hipLaunchKernelGGL(k_boxes, dim3(uint32_t(((1ull << level) + 255) / 256)), block, 0, nullptr, T, level, out.refNodes);
         hipLaunchKernelGGL(k_flatten, gridNodes, block, 0, nullptr, T, out.refNodes, out.nodes);
@@ -982,19 +1017,17 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
         const int capacity = int(std::max<long long>(4ll * n + 64, std::min<long long>(worst, 1ll << 18)));
         SNode* nodes;
         SahCtl* sctl;
-        int *nodeOf, *key, *keyR;
-        Box6 *val, *valR, *pre, *sufR;
+        int* nodeOf;
+        Box6 *pre, *sufR;
         RT_TRY(tmp.get(nodes, size_t(capacity)));
         RT_TRY(tmp.get(sctl, 1));
         RT_TRY(tmp.get(nodeOf, size_t(n)));
-        RT_TRY(tmp.get(key, size_t(n)));
-        RT_TRY(tmp.get(keyR, size_t(n)));
-        RT_TRY(tmp.get(val, size_t(n)));
-        RT_TRY(tmp.get(valR, size_t(n)));
         RT_TRY(tmp.get(pre, size_t(n)));
         RT_TRY(tmp.get(sufR, size_t(n)));
+        const KeyIterator keys(Positions(0), KeyAt { nodeOf, n, 0 }), keysR(Positions(0), KeyAt { nodeOf, n, 1 });
+        const BoxIterator boxes(Positions(0), BoxAt { a, dLo, dHi, n, 0 }), boxesR(Positions(0), BoxAt { a, dLo, dHi, n, 1 });
         size_t boxScanBytes = 0;
-        RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, boxScanBytes, key, val, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+        RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(nullptr, boxScanBytes, keys, boxes, pre, GrowBox(), n, hipcub::Equality(), nullptr));
         char* boxScanTemp;
         RT_TRY(tmp.get(boxScanTemp, boxScanBytes));
         SNode root;
@@ -1014,8 +1047,7 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
         for (int level = 0;; level++) {
             const int first = levelStart[size_t(level)], end = levelStart[size_t(level) + 1];
             const int nOpen = sh.nOpenNext, maxCount = sh.maxCountNext;
-            hipLaunchKernelGGL(k_sah_gather, grid, block, 0, nullptr, a, nodeOf, dLo, dHi, val, key, (Box6*)nullptr, (int*)nullptr, n);
-            RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, key, val, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+            RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, keys, boxes, pre, GrowBox(), n, hipcub::Equality(), nullptr));
             hipLaunchKernelGGL(k_sah_node_boxes, grid, block, 0, nullptr, nodeOf, nodes, pre, more, n);
             if (nOpen == 0) break;
             if (size_t(end - first) > maxSegs) return hipErrorInvalidValue; // cannot happen: a level's nodes have n primitives
@@ -1031,9 +1063,8 @@ hipError_t device_build(const HostScene& scene, const rt_bvh_options& opt, Devic
                 }
                 hipLaunchKernelGGL(k_sort_blocks, grid, block, 0, nullptr, a, blocks, ctl, 0);
                 if (pass == 3) break;
-                hipLaunchKernelGGL(k_sah_gather, grid, block, 0, nullptr, a, nodeOf, dLo, dHi, val, key, valR, keyR, n);
-                RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, key, val, pre, GrowBox(), n, hipcub::Equality(), nullptr));
-                RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, keyR, valR, sufR, GrowBox(), n, hipcub::Equality(), nullptr));
+                RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, keys, boxes, pre, GrowBox(), n, hipcub::Equality(), nullptr));
+                RT_TRY(hipcub::DeviceScan::InclusiveScanByKey(boxScanTemp, boxScanBytes, keysR, boxesR, sufR, GrowBox(), n, hipcub::Equality(), nullptr));
                 hipLaunchKernelGGL(k_sah_eval, grid, block, 0, nullptr, a, nodeOf, nodes, pre, sufR, sctl, n, pass, opt.sah_bins);
             }
             RT_TRY(hipMemsetAsync(&sctl->nOpenNext, 0, 2 * sizeof(int), nullptr));

@@ -118,16 +118,12 @@ def test_several_meshes_and_level_limits(lib):
     meshes = [_grid_mesh(9, 7, seed=1), _generic_mesh(2, seed=5), _grid_mesh(4, 30, seed=2, signed_zeros=True), _generic_mesh(3, seed=9)]
     sc = rt.SceneData(meshes, lights=synth.area_light())
     sh = lib.scene_create(sc)
-    for max_level in (32, 12, 9, 7, 6):
+    for max_level in (32, 12, 9, 7, 6, 2, 1):  # (down to leaves of hundreds of primitives)
         host = lib.bvh_build(sh, max_level=max_level)
         dev, on_device = lib.bvh_build_device(sh, max_level=max_level)
         assert on_device, max_level
         assert _same_tree(lib, host, dev), max_level
         assert _same_frames(lib, sc, host, dev), max_level
-    # leaves of more than 64 primitives: the host builds, same tree
-    host = lib.bvh_build(sh, max_level=2)
-    dev, on_device = lib.bvh_build_device(sh, max_level=2)
-    assert not on_device and _same_tree(lib, host, dev)
 
 
 @pytest.mark.parametrize("scene", ["cornell", "monkey", "teapot", "cube_textured", "single_triangle", "spheres"])
@@ -148,8 +144,8 @@ def test_golden_scenes_build_the_reference_tree(lib, scene):
     assert sah_on_device == on_device and _same_tree(lib, sah_host, sah_dev)
     assert _same_frames(lib, sc, sah_host, sah_dev, rt.features(shading=1, hard_shadow=1, soft_shadow=1, recursive=1))
     cut_host = lib.bvh_build(sh, max_level=2)
-    cut_dev, on_device = lib.bvh_build_device(sh, max_level=2)
-    assert _same_tree(lib, cut_host, cut_dev)
+    cut_dev, cut_on_device = lib.bvh_build_device(sh, max_level=2)
+    assert cut_on_device == on_device and _same_tree(lib, cut_host, cut_dev)
 
 
 def _check_sah(lib, sc, **options):
@@ -234,7 +230,7 @@ def test_triangle_soups_on_a_coarse_grid_both_variants(lib, seed):
             host = lib.bvh_build(sh, **options)
             dev, on_device = lib.bvh_build_device(sh, **options)
             assert _same_tree(lib, host, dev), (n, options)
-            assert on_device or (not options.get("sah") and "max_level" in options), (n, options)
+            assert on_device, (n, options)
             lib.lib.rt_bvh_destroy(host)
             lib.lib.rt_bvh_destroy(dev)
 
