@@ -899,11 +899,6 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
             return v < 1 ? 1 : v;
         }();
         P.primaryStack = primaryStack < b->host.numLevels ? primaryStack : (b->host.numLevels > 0 ? b->host.numLevels : 1);
-        static const int smallPass = [] {
-            const char* e = std::getenv("RT_PRIMARY_SMALL_PASS"); // tuning knob; default chosen by measurement
-            return e ? std::atoi(e) : 40;
-        }();
-        P.primarySmallPass = smallPass;
         static const int streamGroup = [] {
             const char* e = std::getenv("RT_STREAM_GROUP"); // tuning / test knob; default chosen by measurement
             const int v = e ? std::atoi(e) : 2;

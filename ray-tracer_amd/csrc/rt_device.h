@@ -111,7 +111,6 @@ struct FrameParams {
                                        // shadow pass that fills every CU's LDS; the waves it has room for
     int32_t primaryBudget;             // inner nodes a camera ray may visit in the per-lane kernel before it gives up
     int32_t primaryStack;              // ... and the stack entries it may hold
-    int32_t primarySmallPass;          // a pass with fewer tiles per resident wave than this runs with a budget of 32
     size_t queueCapacity;        // entries
     uint8_t* visibility;         // [hit][shadowSamplesPerHit]: 1 = light sample visible
     int32_t shadowSamplesPerHit; // light samples per hit that cast a shadow ray under the current features

@@ -1703,11 +1703,9 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
         FrameParams Q = P;
         Q.primaryChunk = chunk;
         const size_t ldsPrimary = size_t(WAVE) * size_t(P.primaryStack) * sizeof(uint2);
-        // A small pass (a rank's share of a frame on several GPUs) ends when its slowest tile does, and the slowest
-        // tiles are the ones whose rays use up the whole budget: with few tiles per wave a smaller budget shortens
-        // the pass (measured: 1/8 of the headline frame 1.18 -> 1.00 ms), with many it only moves work to the
-        // kernels behind (whole frame 2.69 -> 3.59 ms).
-        if (P.logicalBlocks < waves * uint32_t(P.primarySmallPass) && Q.primaryBudget > 32) Q.primaryBudget = 32;
+        // (A smaller budget for small passes — a rank's share of a frame — was tried and dropped: it shortens this kernel
+        // and lengthens the chain of kernels behind it by more: slowest share of 2 / 4 ranks 6.1 / 3.7 -> 5.3 / 3.3 ms
+        // without it, of 8 ranks the same.)
         launch_walkers(kernel, Q, ldsPrimary, stream);
     }
     auto finish_gave_up = [&](hipStream_t st) {
