@@ -122,7 +122,8 @@ struct rt_scene {
 // pool and gives it back when it returns, so calls on one rt_bvh from several threads (the reference renders one camera
 // per thread from one BvhInterface, src/main.cpp:533-552) run side by side, each on its own set.
 struct RenderScratch {
-    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, shadeList, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux, laneStacks;
+    DevBuf stats, frame, queue, queueCounters, visibility, shadowQueue, shadeList, pairSpill, samples, dofFlags, wfRays, wfNodes, wfMeta, wfValue, wfHits, wfHitNode, wfGlossy, gaveUpQueue, pairSpillAux, laneStacks, lights;
+    std::vector<LightDev> hostLights; // (more than INLINE_LIGHTS lights: what `lights` was filled from)
     hipEvent_t evStart = nullptr, evMid = nullptr, evStop = nullptr, evSplit[4] = { nullptr, nullptr, nullptr, nullptr };
     // second stream (and its fork / join events) on which a direct-lighting pass finishes its long camera rays, and the
     // two marks around that stream's shadow kernel
@@ -877,9 +878,20 @@ rt_status render_rows(const rt_bvh* cb, const rt_camera* camera, const rt_light*
     P.f = *features;
     P.p = *params;
     if (nLights > MAX_LIGHTS) return fail(RT_ERR_LIMIT, "at most " + std::to_string(int(MAX_LIGHTS)) + " lights per frame");
-    fill_lights(lights, nLights, *features, *params, P.lights, P.drawsPerHit);
+    if (nLights <= INLINE_LIGHTS) {
+        fill_lights(lights, nLights, *features, *params, P.lights, P.drawsPerHit);
+        P.shadowSamplesPerHit = number_shadow_samples(P.lights, nLights, *features);
+    } else {
+        // more lights than the kernel argument block has room for: the table goes to device memory, ahead of the
+        // kernels on the call's stream (the host copy belongs to the scratch set and stays until its next call)
+        w->hostLights.resize(size_t(nLights));
+        fill_lights(lights, nLights, *features, *params, w->hostLights.data(), P.drawsPerHit);
+        P.shadowSamplesPerHit = number_shadow_samples(w->hostLights.data(), nLights, *features);
+        RT_HIP(w->lights.reserve(size_t(nLights) * sizeof(LightDev)));
+        RT_HIP(hipMemcpyAsync(w->lights.ptr, w->hostLights.data(), size_t(nLights) * sizeof(LightDev), hipMemcpyHostToDevice, s));
+        P.lightTable = static_cast<const LightDev*>(w->lights.ptr);
+    }
     P.nLights = nLights;
-    P.shadowSamplesPerHit = number_shadow_samples(P.lights, nLights, *features);
     {
         static const int pairStackLds = [] {
             const char* e = std::getenv("RT_PAIR_STACK_LDS"); // tuning / test knob; default chosen by measurement

@@ -26,7 +26,8 @@ struct LightDev {
     int32_t shadowBase; // index of this light's first sample among the hit's shadow-casting samples, or -1
 };
 
-enum { MAX_LIGHTS = 16 };
+enum { INLINE_LIGHTS = 16,  // lights that travel in the kernel argument block; more of them go through device memory
+       MAX_LIGHTS = 4096 };  // (a bound on the table, not a design limit)
 
 // Wavefront evaluation of the reference's recursion (src/render.cpp:18-80): the call tree of every pixel sample of a
 // chunk is laid out as nodes, generation by generation (a generation = the calls at one recursion depth), each
@@ -81,7 +82,8 @@ struct FrameParams {
     int32_t rowsLocal, rowTop, rowBlock, blockStride;
     rt_features f;
     rt_params p;
-    LightDev lights[MAX_LIGHTS]; // travels in the kernel argument block: read with scalar loads, no upload to order
+    LightDev lights[INLINE_LIGHTS]; // travels in the kernel argument block: read with scalar loads, no upload to order
+    const LightDev* lightTable;     // null, or all nLights lights in device memory when there are more than INLINE_LIGHTS
     int32_t nLights;
     int32_t drawsPerHit; // rand() calls one computeLightContribution consumes
     // Output.  One lane evaluates one (pixel, sample) pair.  With a single sample per pixel the colour goes
@@ -139,6 +141,16 @@ struct FrameParams {
     int32_t wfLighting;      // the queue passes read their rays from the nodes and write Lo there
     int32_t wfRootsTurn;     // k_wf_combine: evaluate the pixel samples' own nodes (else: every other node)
 };
+
+// Light i of the frame.  The kernels of the lighting passes are compiled for either home of the lights (TABLE), so that
+// the usual case reads them from the argument block with scalar loads; the others decide at run time.
+template <bool TABLE>
+__device__ __forceinline__ const LightDev& light_in(const FrameParams& P, int i)
+{
+    if (TABLE) return P.lightTable[i];
+    return P.lights[i];
+}
+__device__ __forceinline__ const LightDev& light_at(const FrameParams& P, int i) { return P.lightTable ? P.lightTable[i] : P.lights[i]; }
 
 // Device counters of a pass.  Each sits in a 128-byte line of its own: atomics on one line are served one after the
 // other, and the kernels of a pass hammer different counters at the same time.
@@ -759,7 +771,7 @@ __device__ vec3 light_contribution(const FrameParams& P, const RayD& r, float t,
 {
     vec3 shading = splat3(0.0f);
     for (int li = 0; li < P.nLights; li++) {
-        const LightDev& L = P.lights[li];
+        const LightDev& L = light_at(P, li);
         if (!light_enabled(P, L.type)) continue;
         const bool shadowed = light_shadowed(P, L.type);
         const int total = L.nA * L.nB;

@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <vector>
+#include <type_traits>
 
 namespace rt {
 
@@ -312,6 +313,7 @@ __global__ void k_range(unsigned long long* round, const unsigned long long* beg
 // Those samples get no ray (and their visibility byte stays whatever it was: any finite value times the zero term is
 // the same zero); the others are appended to the shadow work queue, the items
 // of a hit next to each other and hits in queue order (one atomic per wave).
+template <bool TABLE>
 __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
 {
     const unsigned int qBegin = (unsigned int)P.queueCounters[Q_RANGE_BEGIN], nHits = (unsigned int)P.queueCounters[Q_RANGE_END];
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
     uint32_t culled = 0;
     bool everyLightShadowed = true;
     for (int li = 0; li < P.nLights; li++)
-        if (light_enabled(P, P.lights[li].type) && P.lights[li].shadowBase < 0) everyLightShadowed = false;
+        if (light_enabled(P, light_in<TABLE>(P, li).type) && light_in<TABLE>(P, li).shadowBase < 0) everyLightShadowed = false;
     for (unsigned int q = qBegin + blockIdx.x * BLOCK + threadIdx.x; q < rounded; q += gridDim.x * BLOCK) {
         bool live = q < nHits;
         Rng rng;
@@ -359,7 +361,8 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
         uint32_t lightClass = 0;
         if (live && P.f.shading)
             for (int li = 0; li < P.nLights; li++) {
-                const LightDev& L = P.lights[li];
+                if (li >= 16) break; // (two bits per light in one word; further lights are decided sample by sample)
+                const LightDev& L = light_in<TABLE>(P, li);
                 if (L.shadowBase < 0 || L.type == RT_LIGHT_POINT) continue;
                 vec3 corner[4];
                 int corners = 2;
@@ -430,14 +433,14 @@ __global__ void __launch_bounds__(BLOCK) k_cull(const FrameParams P)
             }
             if (live) {
                 for (int li = 0; li < P.nLights; li++) {
-                    const LightDev& L = P.lights[li];
+                    const LightDev& L = light_in<TABLE>(P, li);
                     if (L.shadowBase < 0) continue;
                     const int total = L.nA * L.nB;
                     const uint32_t per = light_draws_per_sample(L.type);
                     for (int k = 0; k < total; k++) {
                         const int j = L.shadowBase + k;
                         bool wanted = true;
-                        const uint32_t decided = (lightClass >> (2 * li)) & 3u;
+                        const uint32_t decided = li < 16 ? (lightClass >> (2 * li)) & 3u : 0u;
                         if (pass == 1 && j < 64) {
                             wanted = (wantedBits >> j) & 1ull;
                         } else if (decided != 0u) {
@@ -780,13 +783,17 @@ __global__ void __launch_bounds__(WAVE, 5) k_stream(const FrameParams P)
                 int sidx;
                 hit_ray(P, work / perHit, e, nPix, rng, cam, pix, sidx);
                 // which light and which of its samples: the last light whose first shadow sample is <= j
-                int li = 0;
-                for (int i = 0; i < P.nLights; i++)
-                    if (P.lights[i].shadowBase >= 0 && P.lights[i].shadowBase <= j) li = i;
-                const LightDev& L = P.lights[li];
-                const int k = j - L.shadowBase;
                 vec3 position, color;
-                light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                auto sample_of = [&](auto home) {
+                    constexpr bool TABLE = decltype(home)::value;
+                    int li = 0;
+                    for (int i = 0; i < P.nLights; i++)
+                        if (light_in<TABLE>(P, i).shadowBase >= 0 && light_in<TABLE>(P, i).shadowBase <= j) li = i;
+                    const LightDev& L = light_in<TABLE>(P, li);
+                    const int k = j - L.shadowBase;
+                    light_sample(L, k, rng.pixelKey, rng.sample, rng.randCounter + uint32_t(L.drawBase) + uint32_t(k) * light_draws_per_sample(L.type), position, color);
+                };
+                if (P.lightTable) sample_of(std::true_type()); else sample_of(std::false_type());
                 const float epsilon = 0.00001f;
                 const vec3 origin = cam.o + (1 - epsilon) * e.t * cam.d;
                 r = make_ray(origin, position - origin);
@@ -1020,6 +1027,7 @@ __global__ void __launch_bounds__(WAVE, 5) k_stream(const FrameParams P)
 // Shade pass: one lane per queued hit — direct lighting with the visibility bits of the shadow pass
 // (reference src/light.cpp:124-220 for a hit whose colour is Lo, src/render.cpp:64-67).  Eight waves per SIMD (64
 // registers): the pass waits on the hit, material and visibility reads of its lanes (0.33 -> 0.30 ms).
+template <bool TABLE>
 __global__ void __launch_bounds__(BLOCK, 8) k_shade(const FrameParams P)
 {
     const unsigned int qBegin = (unsigned int)P.queueCounters[Q_RANGE_BEGIN], nHits = (unsigned int)P.queueCounters[Q_RANGE_END];
@@ -1041,7 +1049,7 @@ __global__ void __launch_bounds__(BLOCK, 8) k_shade(const FrameParams P)
         const uint8_t* vis = P.visibility + size_t(q) * size_t(P.shadowSamplesPerHit);
         vec3 shading = splat3(0.0f);
         for (int li = 0; li < P.nLights; li++) {
-            const LightDev& L = P.lights[li];
+            const LightDev& L = light_in<TABLE>(P, li);
             if (!light_enabled(P, L.type)) continue;
             const bool shadowed = light_shadowed(P, L.type);
             const int total = L.nA * L.nB;
@@ -1737,13 +1745,13 @@ hipError_t launch_split_t(const FrameParams& P, dim3 gridDirect, size_t lds, hip
         else hipLaunchKernelGGL((k_closest<PRUNE, false>), gc, dim3(WAVE), ldsClosest, st, G);
     };
     auto lighting = [&](const FrameParams& R, hipStream_t st, hipEvent_t* marks, hipEvent_t* shadowOnly = nullptr) {
-        if (R.shadowSamplesPerHit > 0) hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, st, R);
+        if (R.shadowSamplesPerHit > 0) hipLaunchKernelGGL(R.lightTable ? k_cull<true> : k_cull<false>, dim3(256 * 8), dim3(BLOCK), 0, st, R);
         if (marks) (void)hipEventRecord(marks[1], st);
         if (shadowOnly) (void)hipEventRecord(shadowOnly[0], st);
         if (R.shadowSamplesPerHit > 0) launch_stream<false>(R, gridDirect.x, streamLds, st);
         if (shadowOnly) (void)hipEventRecord(shadowOnly[1], st);
         if (marks) (void)hipEventRecord(marks[2], st);
-        hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, st, R);
+        hipLaunchKernelGGL(R.lightTable ? k_shade<true> : k_shade<false>, dim3(256 * 8), dim3(BLOCK), 0, st, R);
         if (marks) (void)hipEventRecord(marks[3], st);
     };
     if (!aux) {
@@ -1889,10 +1897,10 @@ hipError_t wavefront_pass(FrameParams& P, int sBegin, int sEnd, size_t lds, hipS
         hipLaunchKernelGGL(k_range, dim3(1), dim3(1), 0, stream, P.queueCounters, (const unsigned long long*)nullptr, (const unsigned long long*)&P.queueCounters[Q_HITS]);
         P.wfLighting = 1;
         if (P.shadowSamplesPerHit > 0) {
-            hipLaunchKernelGGL(k_cull, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+            hipLaunchKernelGGL(P.lightTable ? k_cull<true> : k_cull<false>, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
             launch_stream<false>(P, 256u * 32u, stream_lds_bytes(P.pairStackLds), stream);
         }
-        hipLaunchKernelGGL(k_shade, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
+        hipLaunchKernelGGL(P.lightTable ? k_shade<true> : k_shade<false>, dim3(256 * 8), dim3(BLOCK), 0, stream, P);
         P.wfLighting = 0;
         // values, deepest generation first; the pixel samples' own nodes (in the first range) last
         for (int turn = 0; turn < 2; turn++) {

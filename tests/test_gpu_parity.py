@@ -246,6 +246,50 @@ def test_config5_with_glossy_reflection_matches_oracle(lib):
     assert np.abs(lib.bloom(img.copy(), params) - o.bloom(ref, params)).max() <= 1e-4
 
 
+def _many_lights(count, seed=5):
+    """`count` lights above the scene: point, segment and parallelogram lights in turn, dim enough to keep the sum in range."""
+    rng = np.random.default_rng(seed)
+    rows = np.zeros((count, 22), np.float32)
+    for i in range(count):
+        pos = np.array([rng.uniform(-0.6, 0.6), rng.uniform(0.2, 0.55), rng.uniform(-0.6, 0.6)], np.float32)
+        col = (rng.uniform(0.2, 1.0, 12) * (3.0 / count)).astype(np.float32)
+        kind = i % 3
+        rows[i, 0] = kind
+        if kind == 0:
+            rows[i, 1:7] = [*pos, *col[:3]]
+        elif kind == 1:
+            rows[i, 1:13] = [*pos, *(pos + np.float32([0.15, 0.0, 0.05])), *col[:6]]
+        else:
+            rows[i, 1:22] = [*pos, 0.1, 0.0, 0.0, 0.0, 0.0, 0.1, *col]
+    return rows
+
+
+@pytest.mark.parametrize("count", [16, 17, 40])
+def test_more_lights_than_the_argument_block_holds(lib, count):
+    """The reference has no limit on the number of lights.  Up to 16 travel in the kernel argument block, more go
+    through device memory: direct lighting with hard and soft shadows (queue passes), and with mirror reflection
+    (the bounce paths), against the oracle."""
+    g, sc, orc, sh, bvh = setup(lib, "cornell")
+    rows = _many_lights(count)
+    lights, n = sc.light_array(rows)
+    W, H = 64, 48
+    c = cam("A", (W, H))
+    params = rt.default_params(ray_multiplier=2)
+    for feats in (rt.features(shading=1, hard_shadow=1, soft_shadow=1, multiple_rays=1), rt.features(shading=1, soft_shadow=1, recursive=1)):
+        img, stats = lib.render(bvh, c, lights, n, feats, params, W, H)
+        ref, ostats = orc.render(c, feats, params, W, H, lights=rows)
+        assert np.abs(img - ref).max() <= 2e-5, (count, np.abs(img - ref).max())
+        assert stats.primary_rays == ostats.primary_rays and stats.bounce_rays == ostats.bounce_rays
+    # glossy reflection: the bounce calls as wavefront passes, their lighting through the same queue passes
+    feats = rt.features(shading=1, soft_shadow=1, glossy=1)
+    gparams = rt.default_params(glossy_filter_size=4, ray_depth=2)
+    img, stats = lib.render(bvh, c, lights, n, feats, gparams, W, H)
+    ref, ostats = orc.render(c, feats, gparams, W, H, lights=rows)
+    err = np.abs(img - ref).max(axis=2)
+    assert (err > 1e-4).mean() <= 0.01 and gc.psnr(img, ref) >= 45.0, (count, err.max())
+    assert stats.primary_rays == ostats.primary_rays and stats.bounce_rays == ostats.bounce_rays
+
+
 def test_row_tiles_compose_to_the_full_frame(lib):
     g, sc, orc, sh, bvh = setup(lib, "cornell_para")
     W, H = 80, 56
