@@ -197,3 +197,11 @@ colors = [[1.0, 1.0, 1.0], [1.0, 0.9, 0.8], [0.8, 0.9, 1.0], [1.0, 1.0, 1.0]]
     assert np.array_equal(frames[0], frames[1])
     lit = frames[0].reshape(-1, 3).max(axis=1)
     assert (lit > 0).mean() > 0.05  # the objects are in view and lit
+    # the same picture over the hierarchy of the SAH + binning toggle (built on the GPU by the facade's BvhInterface):
+    # another tree, the same closest hits
+    cfg.write_text(cfg.read_text().replace("[features.extra]\n", "[features.extra]\nenable_bvh_sah_binning = true\n"))
+    res = run_cli([str(cfg), "--gpus", "1"])
+    assert res.returncode == 0, res.stderr
+    files = sorted(glob.glob(str(out / "objects_*_cam_0.bmp")), key=os.path.getmtime)
+    sah = read_bmp(files[-1], 96, 64)
+    assert np.abs(sah.astype(int) - frames[0].astype(int)).max() <= 1 and (sah == frames[0]).mean() >= 0.999
